@@ -1,0 +1,290 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (oracle) of DIGA's backward-free TTA forward path.
+
+This file restates, in plain fp32 torch-CPU / numpy operations, the algorithm of the reference
+(Waybaba/DIGA) for the hot path of SURVEY.md section 8.  It is the *checker*: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.  The product path
+(``diga_amd``) never imports it and fails loudly when the HIP library is missing.
+
+Pinning: ``oracle/gen_golden.py`` imports the reference's own source in the build container and
+writes ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every function below against
+those vectors (<=1e-6 relative for floats, bit-exact for integers).  The reference has no tests or
+fixtures of its own, so with respect to the authors' torch-1.12/cuDNN numerical
+environment parity is unpinned; with respect to the reference source executed by this container's
+torch-2.10 CPU it is pinned by those fixtures.
+
+Reference citations: "ttda" = /root/reference/src/models/ttda_module.py,
+"adaptseg" = /root/reference/src/models/components/adaptseg.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+NUM_CLASSES = 19
+LAYERS = (3, 4, 23, 3)           # adaptseg:242 / ttda:942
+PLANES = (64, 128, 256, 512)     # adaptseg:140-143
+STRIDES = (1, 2, 1, 1)
+DILATIONS = (1, 1, 2, 4)
+
+
+# --------------------------------------------------------------------------------------
+# DAM batch norm  (ttda:299-345, eval branch; installed by DIGA._replace_bn ttda:1814-1833)
+# --------------------------------------------------------------------------------------
+def dam_current_stats(x: torch.Tensor):
+    """Current-batch per-channel statistics with the reference's ``half_first`` rule (ttda:313-320).
+
+    B == 1: plain mean / biased var over (N,H,W).  B > 1: the *average of two group statistics*,
+    group A = sample 0, group B = samples 1..B-1 (NOT the global-batch statistic).
+    """
+    if x.shape[0] > 1:
+        a, b = x[:1], x[1:]
+        mean = (a.mean([0, 2, 3]) + b.mean([0, 2, 3])) / 2
+        var = (a.var([0, 2, 3], unbiased=False) + b.var([0, 2, 3], unbiased=False)) / 2
+    else:
+        mean = x.mean([0, 2, 3])
+        var = x.var([0, 2, 3], unbiased=False)
+    return mean, var
+
+
+def dam_bn(x, running_mean, running_var, weight, bias, lam, eps=1e-5):
+    """y = (x - mean)/sqrt(var+eps)*weight + bias with mean/var = lam*source + (1-lam)*current
+    (ttda:335-343).  No state is written in eval mode."""
+    mean_cur, var_cur = dam_current_stats(x)
+    # lambda_ is an fp32 0-dim tensor in the reference (ttda:369,1812), so (1 - lambda_) is the *fp32*
+    # subtraction 1 - fp32(0.8) = 0.19999999, not fp32(0.2): one ulp that compounds over 104 layers.
+    lam = torch.as_tensor(lam, dtype=torch.float32)
+    mean = lam * running_mean + (1 - lam) * mean_cur
+    var = lam * running_var + (1 - lam) * var_cur
+    y = (x - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + eps)
+    return y * weight[None, :, None, None] + bias[None, :, None, None]
+
+
+# --------------------------------------------------------------------------------------
+# AdaptSegNet DeepLabV2-ResNet101 trunk + 2-branch head  (adaptseg:58-194)
+# --------------------------------------------------------------------------------------
+BN_PRE_HOOK = None   # test/calibration aid: callable(prefix, x, params) run before each BN
+
+
+def _bn(p, prefix, x, lam):
+    if BN_PRE_HOOK is not None:
+        BN_PRE_HOOK(prefix, x, p)
+    return dam_bn(x, p[prefix + ".running_mean"], p[prefix + ".running_var"],
+                  p[prefix + ".weight"], p[prefix + ".bias"], lam)
+
+
+def bottleneck(p, prefix, x, stride, dilation, has_ds, lam, taps=None):
+    """adaptseg:82-102.  Stride sits on the first 1x1 (adaptseg:63); 3x3 has pad = dilation (adaptseg:68-70)."""
+    out = F.conv2d(x, p[prefix + ".conv1.weight"], stride=stride)
+    if taps is not None:
+        taps[prefix + ".conv1"] = out
+    out = torch.relu(_bn(p, prefix + ".bn1", out, lam))
+    out = F.conv2d(out, p[prefix + ".conv2.weight"], padding=dilation, dilation=dilation)
+    if taps is not None:
+        taps[prefix + ".conv2"] = out
+    out = torch.relu(_bn(p, prefix + ".bn2", out, lam))
+    out = F.conv2d(out, p[prefix + ".conv3.weight"])
+    if taps is not None:
+        taps[prefix + ".conv3"] = out
+    out = _bn(p, prefix + ".bn3", out, lam)
+    if has_ds:
+        res = F.conv2d(x, p[prefix + ".downsample.0.weight"], stride=stride)
+        if taps is not None:
+            taps[prefix + ".downsample.0"] = res
+        res = _bn(p, prefix + ".downsample.1", res, lam)
+    else:
+        res = x
+    return torch.relu(out + res)
+
+
+def net_forward_feat(p: dict, x: torch.Tensor, lam: float = 0.8, taps: dict | None = None):
+    """``net(x, feat=True)`` (adaptseg:177-188): returns (layer4 features, logits).
+
+    Head (adaptseg:116-122): the early ``return`` inside the loop means logits =
+    conv_dil6(x) + conv_dil12(x) only; dilations 18/24 are never executed.
+    ``taps`` (optional dict) receives raw conv outputs keyed by the conv's state-dict prefix.
+    """
+    x = F.conv2d(x, p["conv1.weight"], stride=2, padding=3)
+    if taps is not None:
+        taps["conv1"] = x
+    x = torch.relu(_bn(p, "bn1", x, lam))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1, ceil_mode=True)  # adaptseg:139
+    if taps is not None:
+        taps["maxpool"] = x
+    for li, (nb, st, dil) in enumerate(zip(LAYERS, STRIDES, DILATIONS), start=1):
+        for b in range(nb):
+            x = bottleneck(p, f"layer{li}.{b}", x, st if b == 0 else 1, dil, b == 0, lam, taps)
+            if taps is not None:
+                taps[f"layer{li}.{b}"] = x
+    feat = x
+    logits = head_logits(p, feat)
+    return feat, logits
+
+
+def head_logits(p, feat):
+    return (F.conv2d(feat, p["layer6.conv2d_list.0.weight"], p["layer6.conv2d_list.0.bias"], padding=6, dilation=6)
+            + F.conv2d(feat, p["layer6.conv2d_list.1.weight"], p["layer6.conv2d_list.1.bias"], padding=12, dilation=12))
+
+
+# --------------------------------------------------------------------------------------
+# SAM  (ttda:1662-1805)
+# --------------------------------------------------------------------------------------
+def nearest_down_labels(y: torch.Tensor, size) -> torch.Tensor:
+    """ttda:1695 -- F.interpolate(y.float(), mode='nearest') then .long(): src = floor(dst*in/out)."""
+    return F.interpolate(y.unsqueeze(1).float(), size=tuple(size), mode="nearest").squeeze(1).long()
+
+
+def pseudo_labels(logits: torch.Tensor, threshold: float) -> torch.Tensor:
+    """ttda:1662-1676 -- argmax of softmax, 255 where max prob < threshold (strict)."""
+    prob = logits.softmax(dim=1)
+    lab = prob.argmax(dim=1)
+    lab[prob.max(dim=1)[0] < threshold] = 255
+    return lab
+
+
+def class_prototypes(feature: torch.Tensor, labels: torch.Tensor, num_classes: int = NUM_CLASSES):
+    """ttda:1788-1805 -- per-class mean of the feature vectors of pixels with that label.
+    Returns (proto [C,CH], flag [C] in {0,1})."""
+    ch = feature.shape[1]
+    rows = feature.permute(0, 2, 3, 1).reshape(-1, ch)   # same row order as permute/flatten at ttda:1804
+    lab = labels.reshape(-1)
+    proto = torch.zeros(num_classes, ch)
+    flag = torch.zeros(num_classes)
+    for c in range(num_classes):
+        m = lab == c
+        if int(m.sum()) == 0:
+            continue
+        flag[c] = 1
+        proto[c] = rows[m].mean(0)
+    return proto, flag
+
+
+def proto_probs(feature, proto, flag, tau: float = 1.0):
+    """ttda:1712-1734 -- w[b,c,i,j] = exp(-||proto[c]-feature[b,:,i,j]||_2 / tau)*flag[c], normalised
+    over c.  0/0 -> NaN when no class exists or every class underflows (reproduced, not fixed)."""
+    b, ch, h, w = feature.shape
+    c = proto.shape[0]
+    dist = torch.empty(b, c, h, w)
+    for k in range(c):
+        dist[:, k] = torch.norm(proto[k][None, :, None, None] - feature, dim=1)
+    wgt = torch.exp(-dist / tau) * flag[None, :, None, None]
+    return wgt / wgt.sum(dim=1, keepdim=True)
+
+
+def update_running_proto(feature, y_small, run_proto, run_flag, rho, num_classes: int = NUM_CLASSES):
+    """ttda:1736-1765 -- EMA of class prototypes computed from the (down-sampled) *ground-truth*
+    labels; first-seen classes are copied; rho == 0 freezes."""
+    run_proto, run_flag = run_proto.clone(), run_flag.clone()
+    new, has = class_prototypes(feature, y_small, num_classes)
+    for c in range(num_classes):
+        if not has[c] or rho == 0:
+            continue
+        if run_flag[c] == 0:
+            run_proto[c] = new[c]
+            run_flag[c] = 1
+        else:
+            run_proto[c] = (1 - rho) * run_proto[c] + rho * new[c]
+    return run_proto, run_flag
+
+
+class SamState:
+    """The only cross-frame state (ttda:1702-1705): created lazily on the first frame."""
+
+    def __init__(self):
+        self.run_proto = None
+        self.run_flag = None
+
+
+def multi_proto_label(state: SamState, feature, logits, y, cfg, info: dict | None = None):
+    """ttda:1678-1710."""
+    y_small = nearest_down_labels(y, logits.shape[2:])
+    pl = pseudo_labels(logits, cfg["confidence_threshold"])
+    proto, flag = class_prototypes(feature, pl)
+    if state.run_proto is None:
+        state.run_proto, state.run_flag = proto, flag
+    else:
+        state.run_proto, state.run_flag = update_running_proto(
+            feature, y_small, state.run_proto, state.run_flag, cfg["proto_rho"])
+    inst = proto_probs(feature, proto, flag)
+    mean = proto_probs(feature, state.run_proto, state.run_flag)
+    if info is not None:
+        info.update(y_small=y_small, pseudo=pl, inst_proto=proto, inst_flag=flag,
+                    inst_pred=inst, mean_pred=mean)
+    return cfg["proto_lambda"] * mean + (1 - cfg["proto_lambda"]) * inst
+
+
+def fuse(multi_pred, logits, fusion_lambda):
+    """ttda:1644."""
+    return multi_pred * fusion_lambda + logits.softmax(1) * (1 - fusion_lambda)
+
+
+def forward_and_adapt(p, state: SamState, x, y, cfg, info: dict | None = None):
+    """ttda:1623-1645 (without the .cpu())."""
+    feat, logits = net_forward_feat(p, x, cfg["bn_lambda"])
+    if info is not None:
+        info.update(feature=feat, logits=logits)
+    return fuse(multi_proto_label(state, feat, logits, y, cfg, info), logits, cfg["fusion_lambda"])
+
+
+# --------------------------------------------------------------------------------------
+# Tail: upsample + metric  (ttda:1610, 147-211)
+# --------------------------------------------------------------------------------------
+def upsample_probs(probs, size):
+    """ttda:1610 -- nn.Upsample(size, mode='bilinear') == align_corners=False."""
+    return F.interpolate(probs, size=tuple(size), mode="bilinear", align_corners=False)
+
+
+def fast_hist(pred: torch.Tensor, target: torch.Tensor, num_classes: int = NUM_CLASSES):
+    """ttda:168-173 -- rows = target, cols = prediction; targets outside [0,C) ignored."""
+    pred, target = pred.reshape(-1), target.reshape(-1)
+    k = (target >= 0) & (target < num_classes)
+    return torch.bincount(num_classes * target[k].int() + pred[k], minlength=num_classes ** 2).reshape(
+        num_classes, num_classes)
+
+
+def metric_update(hist: torch.Tensor, probs_up: torch.Tensor, target: torch.Tensor):
+    """ttda:158-166 -- hist += fast_hist(argmax) * batch_size."""
+    pred = probs_up.argmax(dim=1)
+    return hist + fast_hist(pred, target) * target.shape[0]
+
+
+IDX16 = [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 15, 17]   # ttda:203 (class 18 omitted as written)
+IDX13 = [0, 1, 2, 6, 7, 8, 10, 11, 12, 13, 15, 17]            # ttda:207
+
+
+def miou(hist: torch.Tensor, kind: str = "default"):
+    """ttda:184-211."""
+    hist = hist.float()
+    d = torch.diag(hist)
+    ious = d / (hist.sum(1) + hist.sum(0) - d)
+    if kind == "16":
+        ious = ious[IDX16]
+    elif kind == "13":
+        ious = ious[IDX13]
+    elif kind != "default":
+        raise NotImplementedError(kind)
+    return torch.nanmean(ious) * 100.0
+
+
+# --------------------------------------------------------------------------------------
+# Checkpoint key remap  (ttda:1000-1016)
+# --------------------------------------------------------------------------------------
+def remap_baseline_keys(saved: dict, model_keys) -> dict:
+    """``load_baseline_pretrained``: file ``layer5.*`` -> model ``layer6.*``; other ``layer*`` keys
+    verbatim; remaining keys copied if the model has them, else ValueError."""
+    out = {}
+    for k, v in saved.items():
+        head = k.split(".")[0]
+        if head == "layer5":
+            out["layer6." + k.split(".", 1)[1]] = v
+        elif "layer" in head:
+            out[k] = v
+        elif k in model_keys:
+            out[k] = v
+        else:
+            raise ValueError("Can not find pretrained model type.")
+    return out
+
+
+def to_torch(params: dict) -> dict:
+    return {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k, v in params.items()}

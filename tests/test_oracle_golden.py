@@ -1,0 +1,198 @@
+"""Pins oracle/diga_oracle.py (the CPU restatement) to golden vectors produced by running the
+reference's own source (oracle/gen_golden.py).  Floats <= 1e-6 relative to the tensor scale, integers
+bit-exact.  CPU only."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD
+from diga_amd import synth
+from oracle import diga_oracle as O
+
+CFG = dict(bn_lambda=0.8, proto_lambda=0.8, fusion_lambda=0.8, confidence_threshold=0.9, proto_rho=0.1)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def close(a, b, rtol=1e-6, atol_scale=1e-6):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape
+    assert np.array_equal(np.isnan(a), np.isnan(b)), "NaN pattern differs"
+    m = ~np.isnan(a)
+    scale = max(float(np.abs(b[m]).max()), 1e-30) if m.any() else 1.0
+    err = np.abs(a[m] - b[m])
+    assert (err <= rtol * np.abs(b[m]) + atol_scale * scale).all(), float(err.max() / scale)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("B", [1, 2, 3])
+def test_dam_bn(gold_bn, B):
+    g = gold_bn
+    y = O.dam_bn(T(g[f"B{B}_x"]), T(g[f"B{B}_running_mean"]), T(g[f"B{B}_running_var"]), T(g[f"B{B}_weight"]),
+                 T(g[f"B{B}_bias"]), 0.8)
+    close(y.numpy(), g[f"B{B}_y"])
+
+
+def test_pseudo_labels(gold_sam):
+    pl = O.pseudo_labels(T(gold_sam["pl_logits"]), 0.9)
+    assert np.array_equal(pl.numpy(), gold_sam["pl_labels"])
+    assert pl.dtype == torch.int64
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_class_prototypes(gold_sam, B):
+    proto, flag = O.class_prototypes(T(gold_sam[f"cp{B}_feat"]), T(gold_sam[f"cp{B}_lab"]))
+    assert np.array_equal(flag.numpy(), gold_sam[f"cp{B}_flag"])
+    close(proto.numpy(), gold_sam[f"cp{B}_proto"])
+
+
+def test_update_running_proto(gold_sam):
+    g = gold_sam
+    for tag, rho in (("rho01", 0.1), ("rho0", 0)):
+        r, f = O.update_running_proto(T(g["up_feat"]), T(g["up_y"]), T(g["up_run"]), T(g["up_flag"]), rho)
+        assert np.array_equal(f.numpy(), g[f"up_flag_{tag}"])
+        close(r.numpy(), g[f"up_run_{tag}"])
+
+
+def test_proto_probs(gold_sam):
+    g = gold_sam
+    feat, proto, flag = T(g["pp_feat"]), T(g["pp_proto"]), T(g["pp_flag"])
+    close(O.proto_probs(feat, proto, flag).numpy(), g["pp_w"], rtol=2e-5)
+    w0 = O.proto_probs(feat, proto, torch.zeros(19)).numpy()
+    assert np.isnan(w0).all() and np.isnan(g["pp_w_zero"]).all()
+    close(O.proto_probs(feat, T(g["pp_far"]), flag).numpy(), g["pp_w_far"], rtol=2e-5)
+    close(O.proto_probs(feat, proto + 30.0, flag).numpy(), g["pp_w_allfar"], rtol=2e-5)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_multi_proto_label_sequence(gold_sam, B):
+    g = gold_sam
+    st = O.SamState()
+    for t in range(3):
+        feat, lg, y = T(g[f"mpl{B}_{t}_feat"]), T(g[f"mpl{B}_{t}_logits"]), T(g[f"mpl{B}_{t}_y"])
+        mp = O.multi_proto_label(st, feat, lg, y, CFG)
+        close(mp.numpy(), g[f"mpl{B}_{t}_multi"], rtol=2e-5)
+        close(O.fuse(mp, lg, 0.8).numpy(), g[f"mpl{B}_{t}_fused"], rtol=2e-5)
+        close(st.run_proto.numpy(), g[f"mpl{B}_{t}_run"])
+        assert np.array_equal(st.run_flag.numpy(), g[f"mpl{B}_{t}_rflag"])
+
+
+def test_nearest_down(gold_tail):
+    g = gold_tail
+    for n in "abc":
+        H, W, h, w = g[f"nd_{n}_shape"]
+        y = T(g[f"nd_{n}_y"].astype(np.int64))
+        assert np.array_equal(O.nearest_down_labels(y, (h, w)).numpy(), g[f"nd_{n}_ys"])
+
+
+def test_tail_upsample_metric(gold_tail):
+    g = gold_tail
+    up = O.upsample_probs(T(g["tail_probs"]), (65, 129))
+    close(up.numpy(), g["tail_up"])
+    assert np.array_equal(up.argmax(1).numpy(), g["tail_argmax"])
+    tgt = T(g["tail_tgt"])
+    h = O.metric_update(torch.zeros(19, 19), up, tgt)
+    assert np.array_equal(h.numpy(), g["tail_hist1"])
+    h = O.metric_update(h, up.flip(0), tgt)
+    assert np.array_equal(h.numpy(), g["tail_hist2"])
+    got = [float(O.miou(h, k)) for k in ("default", "16", "13")]
+    np.testing.assert_allclose(got, g["tail_miou"], rtol=1e-6)
+
+
+def _run_sequence(p, B, H, W, nframes):
+    st = O.SamState()
+    hist = torch.zeros(19, 19)
+    out = []
+    for t in range(nframes):
+        x, y = synth.synth_frame(t, B, H, W)
+        info = {}
+        with torch.no_grad():
+            probs = O.forward_and_adapt(p, st, T(x), T(y), CFG, info)
+            up = O.upsample_probs(probs, y.shape[-2:])
+            hist = O.metric_update(hist, up, T(y))
+        out.append(dict(x=x, probs=probs, pred=up.argmax(1), hist=hist.clone(), run=st.run_proto.clone(),
+                        rflag=st.run_flag.clone(), **info))
+    return out, hist
+
+
+@pytest.mark.parametrize("tag", ["s1", "s2", "s3", "m1"])
+def test_whole_net_small(gold_small, synth_params_np, tag):
+    g = gold_small
+    p = O.to_torch(synth_params_np)
+    B, H, W = (int(v) for v in g[f"{tag}_shape"])
+    res, hist = _run_sequence(p, B, H, W, 3)
+    for t, r in enumerate(res):
+        assert sha(r["x"]) == str(g[f"{tag}_{t}_x_sha"]), "synthetic frame did not regenerate bit-identically"
+        close(r["logits"].numpy(), g[f"{tag}_{t}_logits"], rtol=1e-4, atol_scale=2e-5)
+        close(r["feature"][:, ::16].numpy(), g[f"{tag}_{t}_feat_sub"], rtol=1e-4, atol_scale=2e-5)
+        assert np.array_equal(r["pseudo"].numpy(), g[f"{tag}_{t}_pseudo"])
+        close(r["probs"].numpy(), g[f"{tag}_{t}_probs"], rtol=1e-3, atol_scale=1e-4)
+        assert np.array_equal(r["pred"].numpy().astype(np.uint8), g[f"{tag}_{t}_pred"])
+        close(r["run"].numpy(), g[f"{tag}_{t}_run"], rtol=1e-4, atol_scale=2e-5)
+        assert np.array_equal(r["rflag"].numpy(), g[f"{tag}_{t}_rflag"])
+        assert np.array_equal(r["hist"].numpy(), g[f"{tag}_{t}_hist"])
+    got = [float(O.miou(hist, k)) for k in ("default", "16", "13")]
+    np.testing.assert_allclose(got, g[f"{tag}_miou"], rtol=1e-6)
+
+
+def test_whole_net_taps(gold_small, synth_params_np):
+    g = gold_small
+    p = O.to_torch(synth_params_np)
+    x, _ = synth.synth_frame(0, 1, 65, 129)
+    taps = {}
+    with torch.no_grad():
+        O.net_forward_feat(p, T(x), 0.8, taps)
+    for k in ("conv1", "maxpool", "layer1.0.conv1", "layer1.0.conv2", "layer1.0", "layer2.0.conv1", "layer2.3",
+              "layer3.0.conv2", "layer3.22", "layer4.0.conv2"):
+        ref = g[f"s1_tap_{k}"]
+        got = taps[k].numpy()
+        if ref.shape[1] != got.shape[1]:
+            got = got[:, ::4]
+        close(got, ref, rtol=1e-4, atol_scale=2e-5)
+
+
+def test_loader_remap():
+    with open(os.path.join(GOLD, "loader.json")) as f:
+        rec = json.load(f)
+    p = synth.synth_params(0)
+    saved = {}
+    for k, v in p.items():
+        if k.startswith("layer5."):
+            continue
+        saved[("layer5." + k.split(".", 1)[1]) if k.startswith("layer6.") else k] = v
+    assert len(saved) == rec["file_keys"]
+    out = O.remap_baseline_keys(saved, set(p.keys()))
+    for k, h in rec["checks"].items():
+        assert sha(out[k]) == h
+    assert not any(k.startswith("layer5.") for k in out)
+    bad = dict(saved)
+    bad["mystery.weight"] = np.zeros(1)
+    with pytest.raises(ValueError, match=rec["bad_key_error"]):
+        O.remap_baseline_keys(bad, set(p.keys()))
+
+
+def test_whole_net_full_res(gold_full, synth_params_np):
+    """Two full 1024x512 frames (seed branch + EMA branch) against the reference's outputs."""
+    g = gold_full
+    p = O.to_torch(synth_params_np)
+    res, hist = _run_sequence(p, 1, 512, 1024, 2)
+    for t, r in enumerate(res):
+        assert sha(r["x"]) == str(g[f"{t}_x_sha"])
+        close(r["logits"].numpy(), g[f"{t}_logits"], rtol=1e-4, atol_scale=2e-5)
+        close(r["feature"][:, ::16, ::4, ::4].numpy(), g[f"{t}_feat_sub"], rtol=1e-4, atol_scale=2e-5)
+        assert np.array_equal(r["pseudo"].numpy(), g[f"{t}_pseudo"])
+        close(r["probs"].numpy(), g[f"{t}_probs"], rtol=1e-3, atol_scale=1e-4)
+        assert np.array_equal(r["pred"].numpy().astype(np.uint8), g[f"{t}_pred"])
+        close(r["run"].numpy(), g[f"{t}_run"], rtol=1e-4, atol_scale=2e-5)
+        assert np.array_equal(r["hist"].numpy(), g[f"{t}_hist"])
+    got = [float(O.miou(hist, k)) for k in ("default", "16", "13")]
+    np.testing.assert_allclose(got, g["miou"], rtol=1e-6)
