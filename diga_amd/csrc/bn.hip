@@ -1,0 +1,287 @@
+// DAM batch norm (SIFABatchNorm2d.forward eval branch, ttda_module.py:299-345) split for the GPU:
+//   conv epilogue / stem  -> per-tile shifted sums (slab)
+//   diga_bn_finalize      -> fixed-order slab reduce + lambda-mix with the source statistics -> scale/shift
+//   diga_bn_apply         -> y = relu(raw*scale + shift (+ residual))   (HBM/L2-bound elementwise)
+//   diga_bn_relu_maxpool  -> the stem's bn1 + ReLU + ceil-mode max pool in one pass
+#include "common.h"
+
+namespace {
+
+__global__ void bn_finalize_kernel(const float* __restrict__ slab, int ntiles, int C, double n_a, double n_b,
+                                   const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                   const float* __restrict__ weight, const float* __restrict__ bias, float lam,
+                                   float eps, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  // fixed tile order, fp64 accumulation of the fp32 per-tile partials -> deterministic
+  double s[4] = {0, 0, 0, 0};
+  for (int t = 0; t < ntiles; ++t) {
+    const float* q = slab + (size_t)t * 4 * C + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] += (double)q[k * C];
+  }
+  const double K = (double)rmean[c];
+  const double ma = s[0] / n_a;
+  float mean_cur = (float)(K + ma);
+  float var_cur = (float)(s[1] / n_a - ma * ma);
+  if (n_b > 0) {
+    const double mb = s[2] / n_b;
+    const float mean_b = (float)(K + mb);
+    const float var_b = (float)(s[3] / n_b - mb * mb);
+    mean_cur = (mean_cur + mean_b) / 2.f;   // ttda:316-317 (fp32)
+    var_cur = (var_cur + var_b) / 2.f;
+  }
+  const float oml = 1.f - lam;              // fp32 subtraction, as the reference's tensor op (ttda:335)
+  const float mean = lam * rmean[c] + oml * mean_cur;
+  const float var = lam * rvar[c] + oml * var_cur;
+  const float sc = weight[c] / sqrtf(var + eps);
+  scale[c] = sc;
+  shift[c] = bias[c] - mean * sc;
+}
+
+__global__ void bn_reduce_slab_kernel(const float* __restrict__ slab, int ntiles, int C, float* __restrict__ sums) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // over 4*C
+  if (e >= 4 * C) return;
+  double s = 0;
+  for (int t = 0; t < ntiles; ++t) s += (double)slab[(size_t)t * 4 * C + e];
+  sums[e] = (float)s;
+}
+
+// rows x C elementwise.  A thread owns one 8-channel octet (16 B) and walks rows, so its 8 scale/shift
+// pairs stay in registers; consecutive threads take consecutive octets of a row (coalesced 16-B accesses).
+// MODE 0: no residual, 1: normalised residual, 2: raw residual with its own affine (downsample branch).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const u32x4* __restrict__ raw, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const u32x4* __restrict__ res,
+                                                       const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                       u32x4* __restrict__ out, int64_t M, int C8, int relu,
+                                                       int rows_per_block) {
+  const int oct = threadIdx.x % C8, rsub = threadIdx.x / C8, rstep = 256 / C8;
+  float sc[8], sh[8], rsc[8], rsh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sc[i] = scale[oct * 8 + i];
+    sh[i] = shift[oct * 8 + i];
+    if (MODE == 2) {
+      rsc[i] = rscale[oct * 8 + i];
+      rsh[i] = rshift[oct * 8 + i];
+    }
+  }
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t row1 = row0 + rows_per_block < M ? row0 + rows_per_block : M;
+  for (int64_t r = row0 + rsub; r < row1; r += rstep) {
+    const int64_t idx = r * C8 + oct;
+    float v[8], q[8];
+    unpack_bf16x8(raw[idx], v);
+    if (MODE != 0) unpack_bf16x8(res[idx], q);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float y = fmaf(v[i], sc[i], sh[i]);
+      if (MODE == 1) y += q[i];
+      if (MODE == 2) y += fmaf(q[i], rsc[i], rsh[i]);
+      v[i] = relu ? fmaxf(y, 0.f) : y;
+    }
+    out[idx] = pack_bf16x8(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const u32x4* __restrict__ raw, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, u32x4* __restrict__ out,
+                                                              int B, int H, int W, int C8, int Ho, int Wo) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * Ho * Wo * C8;
+  if (idx >= total) return;
+  const int oct = (int)(idx % C8);
+  int64_t pix = idx / C8;
+  const int ow = (int)(pix % Wo);
+  pix /= Wo;
+  const int oh = (int)(pix % Ho), n = (int)(pix / Ho);
+  float sc[8], sh[8], best[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sc[i] = scale[oct * 8 + i];
+    sh[i] = shift[oct * 8 + i];
+    best[i] = -INFINITY;
+  }
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int ih = oh * 2 - 1 + kh;
+    if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int iw = ow * 2 - 1 + kw;
+      if ((unsigned)iw >= (unsigned)W) continue;
+      float v[8];
+      unpack_bf16x8(raw[((int64_t)(n * H + ih) * W + iw) * C8 + oct], v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) best[i] = fmaxf(best[i], fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f));
+    }
+  }
+  out[idx] = pack_bf16x8(best);
+}
+
+// [B][HW][C] bf16 -> [B][C][HW] fp32 through a 32x32 LDS tile
+__global__ void nhwc_to_nchw_kernel(const unsigned short* __restrict__ in, float* __restrict__ out, int HW, int C) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int p = p0 + i, c = c0 + tx;
+    t[i][tx] = (p < HW && c < C) ? bf16_bits_to_f32(in[((size_t)b * HW + p) * C + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, p = p0 + tx;
+    if (p < HW && c < C) out[((size_t)b * C + c) * HW + p] = t[tx][i];
+  }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int HW, int C) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, p = p0 + tx;
+    t[i][tx] = (p < HW && c < C) ? in[((size_t)b * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int p = p0 + i, c = c0 + tx;
+    if (p < HW && c < C) out[((size_t)b * HW + p) * C + c] = f32_to_bf16_bits(t[tx][i]);
+  }
+}
+
+// Stand-alone DAM statistics for an fp32 NCHW tensor (the SIFABatchNorm2d module used on its own):
+// one block per channel; per-thread shifted sums, 64-lane wavefront shuffle reduction, then a fixed-order
+// combine of the 4 waves through LDS.  Writes a 1-tile slab that diga_bn_finalize consumes.
+__global__ __launch_bounds__(256) void bn_stats_nchw_kernel(const float* __restrict__ x, int B, int C, int HW, int split_b,
+                                                            const float* __restrict__ shift, float* __restrict__ slab) {
+  __shared__ double red[4][4];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float K = shift[c];
+  double acc[4] = {0, 0, 0, 0};
+  for (int b = 0; b < B; ++b) {
+    const float* p = x + ((size_t)b * C + c) * HW;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < HW; i += 256) {
+      const float d = p[i] - K;
+      s1 += d;
+      s2 = fmaf(d, d, s2);
+    }
+    const int g = b < split_b ? 0 : 1;
+    acc[g * 2] += (double)s1;
+    acc[g * 2 + 1] += (double)s2;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+    if (lane == 0) red[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (tid < 4) slab[(size_t)tid * C + c] = (float)(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
+__global__ void bn_apply_nchw_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                     float* __restrict__ out, int C, int HW, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)((i / HW) % C);
+  out[i] = fmaf(x[i], scale[c], shift[c]);
+}
+
+}  // namespace
+
+extern "C" int diga_bn_finalize(const float* slab, int ntiles, int C, double n_a, double n_b, const float* running_mean,
+                                const float* running_var, const float* weight, const float* bias, float lam, float eps,
+                                float* scale, float* shift, void* stream) {
+  DIGA_CHECK_ARG(slab && running_mean && running_var && weight && bias && scale && shift, "diga_bn_finalize: NULL pointer");
+  DIGA_CHECK_ARG(ntiles > 0 && C > 0 && n_a > 0 && n_b >= 0, "diga_bn_finalize: bad sizes ntiles=%d C=%d", ntiles, C);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, slab, ntiles, C, n_a, n_b,
+                     running_mean, running_var, weight, bias, lam, eps, scale, shift);
+  DIGA_CHECK_LAUNCH("diga_bn_finalize");
+  return DIGA_OK;
+}
+
+extern "C" int diga_bn_reduce_slab(const float* slab, int ntiles, int C, float* sums, void* stream) {
+  DIGA_CHECK_ARG(slab && sums && ntiles > 0 && C > 0, "diga_bn_reduce_slab: bad argument");
+  hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(cdiv(4 * C, 64)), dim3(64), 0, (hipStream_t)stream, slab, ntiles, C, sums);
+  DIGA_CHECK_LAUNCH("diga_bn_reduce_slab");
+  return DIGA_OK;
+}
+
+extern "C" int diga_bn_apply(const void* raw, const float* scale, const float* shift, const void* res,
+                             const float* res_scale, const float* res_shift, void* out, int64_t M, int C, int relu,
+                             void* stream) {
+  DIGA_CHECK_ARG(raw && scale && shift && out, "diga_bn_apply: NULL pointer");
+  DIGA_CHECK_ARG(M > 0 && C >= 64 && C <= 2048 && (C & (C - 1)) == 0, "diga_bn_apply: C=%d must be a power of two in [64,2048]", C);
+  DIGA_CHECK_ARG((res_scale == nullptr) == (res_shift == nullptr), "diga_bn_apply: res_scale/res_shift go together");
+  DIGA_CHECK_ARG(res != nullptr || res_scale == nullptr, "diga_bn_apply: residual affine without residual");
+  const int C8 = C / 8, rstep = 256 / C8;
+  int rpb = cdiv(M, 2048);
+  rpb = cdiv(rpb, rstep) * rstep;
+  const dim3 grid(cdiv(M, rpb)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const u32x4* r = (const u32x4*)raw;
+  const u32x4* q = (const u32x4*)res;
+  if (!res)
+    hipLaunchKernelGGL(bn_apply_kernel<0>, grid, block, 0, st, r, scale, shift, q, res_scale, res_shift, (u32x4*)out, M, C8, relu, rpb);
+  else if (!res_scale)
+    hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, st, r, scale, shift, q, res_scale, res_shift, (u32x4*)out, M, C8, relu, rpb);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<2>, grid, block, 0, st, r, scale, shift, q, res_scale, res_shift, (u32x4*)out, M, C8, relu, rpb);
+  DIGA_CHECK_LAUNCH("diga_bn_apply");
+  return DIGA_OK;
+}
+
+extern "C" int diga_bn_relu_maxpool(const void* raw, const float* scale, const float* shift, void* out, int B, int H, int W,
+                                    int C, int Ho, int Wo, void* stream) {
+  DIGA_CHECK_ARG(raw && scale && shift && out, "diga_bn_relu_maxpool: NULL pointer");
+  DIGA_CHECK_ARG(B > 0 && H > 1 && W > 1 && C % 8 == 0, "diga_bn_relu_maxpool: bad dims");
+  // PyTorch ceil_mode rule for k=3, s=2, p=1: o = ceil((H-1)/2)+1, minus one if the last window starts beyond the input
+  auto osz = [](int L) {
+    int o = (L + 2 - 3 + 1) / 2 + 1;
+    if ((o - 1) * 2 >= L + 1) --o;
+    return o;
+  };
+  DIGA_CHECK_ARG(Ho == osz(H) && Wo == osz(W), "diga_bn_relu_maxpool: output %dx%d does not match ceil-mode pooling of %dx%d", Ho, Wo, H, W);
+  const int64_t total = (int64_t)B * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)raw, scale,
+                     shift, (u32x4*)out, B, H, W, C / 8, Ho, Wo);
+  DIGA_CHECK_LAUNCH("diga_bn_relu_maxpool");
+  return DIGA_OK;
+}
+
+extern "C" int diga_nhwc_bf16_to_nchw_f32(const void* in, float* out, int B, int HW, int C, void* stream) {
+  DIGA_CHECK_ARG(in && out && B > 0 && HW > 0 && C > 0, "diga_nhwc_bf16_to_nchw_f32: bad argument");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)in, out, HW, C);
+  DIGA_CHECK_LAUNCH("diga_nhwc_bf16_to_nchw_f32");
+  return DIGA_OK;
+}
+
+extern "C" int diga_nchw_f32_to_nhwc_bf16(const float* in, void* out, int B, int HW, int C, void* stream) {
+  DIGA_CHECK_ARG(in && out && B > 0 && HW > 0 && C > 0, "diga_nchw_f32_to_nhwc_bf16: bad argument");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, in,
+                     (unsigned short*)out, HW, C);
+  DIGA_CHECK_LAUNCH("diga_nchw_f32_to_nhwc_bf16");
+  return DIGA_OK;
+}
+
+extern "C" int diga_bn_stats_nchw_f32(const float* x, int B, int C, int HW, int split_b, const float* stat_shift, float* slab,
+                                      void* stream) {
+  DIGA_CHECK_ARG(x && stat_shift && slab && B > 0 && C > 0 && HW > 0 && split_b >= 0 && split_b <= B, "diga_bn_stats_nchw_f32: bad argument");
+  hipLaunchKernelGGL(bn_stats_nchw_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, B, C, HW, split_b, stat_shift, slab);
+  DIGA_CHECK_LAUNCH("diga_bn_stats_nchw_f32");
+  return DIGA_OK;
+}
+
+extern "C" int diga_bn_apply_nchw_f32(const float* x, const float* scale, const float* shift, float* out, int B, int C, int HW,
+                                      void* stream) {
+  DIGA_CHECK_ARG(x && scale && shift && out && B > 0 && C > 0 && HW > 0, "diga_bn_apply_nchw_f32: bad argument");
+  const int64_t total = (int64_t)B * C * HW;
+  hipLaunchKernelGGL(bn_apply_nchw_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out, C, HW,
+                     total);
+  DIGA_CHECK_LAUNCH("diga_bn_apply_nchw_f32");
+  return DIGA_OK;
+}

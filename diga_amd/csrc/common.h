@@ -1,0 +1,59 @@
+// Internal helpers shared by the kernel translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/diga_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+void diga_set_error(const char* fmt, ...);
+
+#define DIGA_CHECK_ARG(cond, ...)      \
+  do {                                 \
+    if (!(cond)) {                     \
+      diga_set_error(__VA_ARGS__);     \
+      return DIGA_EINVAL;              \
+    }                                  \
+  } while (0)
+
+#define DIGA_CHECK_LAUNCH(name)                                              \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      diga_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return DIGA_ELAUNCH;                                                   \
+    }                                                                        \
+  } while (0)
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+  return __uint_as_float(((unsigned int)b) << 16);
+}
+// round-to-nearest-even fp32 -> bf16 (v_cvt_pk_bf16_f32 on gfx950; keeps NaN a NaN)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+}
+__device__ __forceinline__ void unpack_bf16x8(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack_bf16x8(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,386 @@
+// Semantic Adaptation Module kernels (ttda_module.py:1662-1805) and the fusion line (ttda:1644).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// head finish + pseudo labels  (ttda:1662-1676)
+// One thread per pixel: logits = sum of split-K partials + (bias_d6 + bias_d12); softmax over the
+// C classes in fixed class order; label = argmax (lowest index on ties, NaN counts as maximal, as
+// torch.argmax does) and 255 where max prob < threshold (strict).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_finish_pl_kernel(const float* __restrict__ partials, int splitk, int cpad,
+                                                             const float* __restrict__ bias, const float* __restrict__ logits_in,
+                                                             float* __restrict__ logits_out, int32_t* __restrict__ labels,
+                                                             int64_t P, int C, int hw, float thr) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int64_t b = p / hw, pix = p - b * hw;
+  float l[DIGA_NUM_CLASSES_MAX];
+  if (partials) {
+    for (int c = 0; c < C; ++c) {
+      float v = 0.f;
+      for (int s = 0; s < splitk; ++s) v += partials[((size_t)s * P + p) * cpad + c];
+      l[c] = v + bias[c];
+    }
+  } else {
+    for (int c = 0; c < C; ++c) l[c] = logits_in[((size_t)b * C + c) * hw + pix];
+  }
+  if (logits_out)
+    for (int c = 0; c < C; ++c) logits_out[((size_t)b * C + c) * hw + pix] = l[c];
+  float mx = l[0];
+  int am = 0;
+  for (int c = 1; c < C; ++c) {
+    const bool better = (l[c] > mx) || (l[c] != l[c] && mx == mx);
+    if (better) {
+      mx = l[c];
+      am = c;
+    }
+  }
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) sum += expf(l[c] - mx);
+  const float pmax = 1.0f / sum;        // exp(0)/sum
+  labels[p] = (pmax < thr) ? 255 : am;  // NaN < thr is false -> keeps argmax, as the reference
+}
+
+// ---------------------------------------------------------------------------------------------
+// nearest down-sampling of the label map (ttda:1695)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+  if (in == out) return dst;
+  if (in * 2 == out) return dst >> 1;
+  const float scale = (float)in / (float)out;
+  const int s = (int)floorf((float)dst * scale);
+  return s < in - 1 ? s : in - 1;
+}
+
+template <typename T>
+__global__ void nearest_down_kernel(const T* __restrict__ y, int32_t* __restrict__ out, int B, int H, int W, int h, int w) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * h * w) return;
+  const int ox = (int)(i % w), oy = (int)((i / w) % h), b = (int)(i / ((int64_t)w * h));
+  out[i] = (int32_t)y[((size_t)b * H + nearest_src(oy, H, h)) * W + nearest_src(ox, W, w)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// prototype pooling (cal_proto, ttda:1788-1805)
+//   1. index: one wave per (set, class) walks the label array in pixel order and writes the stable list
+//      of pixel ids of that class (ballot + popcount compaction)                       -> idx, counts
+//   2. pool : block (chunk j, class c, set s): each wave owns a 512-channel slice (8 per lane) and sums the
+//      feature rows of list positions [j*CS, (j+1)*CS) in registers                   -> partial[s][c][j][CH]
+//   3. reduce: sums[s][c][ch] = sum_j partial (fixed order)                            -> deterministic
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void proto_index_kernel(const int32_t* __restrict__ labels, int64_t P, int C,
+                                                         int32_t* __restrict__ idx, int32_t* __restrict__ counts) {
+  const int c = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+  const int32_t* lab = labels + (size_t)s * P;
+  int32_t* list = idx + ((size_t)s * C + c) * P;
+  int count = 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int64_t base = 0; base < P; base += 256) {
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t p = base + lane * 4 + j;
+      v[j] = p < P ? lab[p] : -1;
+    }
+    unsigned long long m[4];
+    int before = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m[j] = __ballot(v[j] == c);
+      before += __popcll(m[j] & below);
+      total += __popcll(m[j]);
+    }
+    int pos = count + before;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (v[j] == c) list[pos++] = (int32_t)(base + lane * 4 + j);
+    }
+    count += total;
+  }
+  if (lane == 0) counts[s * C + c] = count;
+}
+
+__global__ __launch_bounds__(256) void proto_pool_kernel(const unsigned short* __restrict__ feat, const int32_t* __restrict__ idx,
+                                                         const int32_t* __restrict__ counts, int64_t P, int C, int CH, int CS,
+                                                         int JC, float* __restrict__ partial) {
+  const int j = blockIdx.x, c = blockIdx.y, s = blockIdx.z;
+  const int n = counts[s * C + c];
+  const int beg = j * CS;
+  if (beg >= n) return;
+  const int end = min(beg + CS, n);
+  const int32_t* list = idx + ((size_t)s * C + c) * P;
+  float* dst = partial + (((size_t)s * C + c) * JC + j) * CH;
+  for (int ch0 = threadIdx.x * 8; ch0 < CH; ch0 += 2048) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    int q = beg;
+    for (; q + 4 <= end; q += 4) {
+      u32x4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const u32x4*>(feat + (size_t)list[q + u] * CH + ch0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[8];
+        unpack_bf16x8(r[u], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += f[i];
+      }
+    }
+    for (; q < end; ++q) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const u32x4*>(feat + (size_t)list[q] * CH + ch0), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += f[i];
+    }
+    *reinterpret_cast<f32x4*>(dst + ch0) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4*>(dst + ch0 + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+  }
+}
+
+__global__ void proto_reduce_kernel(const float* __restrict__ partial, const int32_t* __restrict__ counts, int C, int CH, int CS,
+                                    int JC, float* __restrict__ sums) {
+  const int sc = blockIdx.y;                                   // s*C + c
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= CH) return;
+  const int n = counts[sc];
+  const int nj = (n + CS - 1) / CS;
+  float v = 0.f;
+  for (int j = 0; j < nj; ++j) v += partial[((size_t)sc * JC + j) * CH + ch];
+  sums[(size_t)sc * CH + ch] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// instance prototypes + running-prototype seed / EMA (ttda:1700-1705, 1736-1765)
+// ---------------------------------------------------------------------------------------------
+__global__ void proto_update_kernel(const float* __restrict__ sums, const int32_t* __restrict__ counts, int C, int CH,
+                                    float* __restrict__ inst_proto, float* __restrict__ inst_flag, float* __restrict__ run_proto,
+                                    float* __restrict__ run_flag, const int32_t* __restrict__ state_flag, float omr, float rho) {
+  const int c = blockIdx.y;
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= CH) return;
+  const int n_pl = counts[c], n_gt = counts[C + c];
+  const float inst = n_pl > 0 ? sums[(size_t)c * CH + ch] / (float)n_pl : 0.f;   // .mean(0): sum / n
+  inst_proto[(size_t)c * CH + ch] = inst;
+  const bool seeded = *state_flag != 0;
+  float run = run_proto[(size_t)c * CH + ch];
+  const float rf = run_flag[c];
+  float new_flag = rf;
+  if (!seeded) {                      // first frame: running := instance (ttda:1702-1703)
+    run = inst;
+    new_flag = n_pl > 0 ? 1.f : 0.f;
+  } else if (n_gt > 0 && rho != 0.f) {
+    const float gt = sums[((size_t)C + c) * CH + ch] / (float)n_gt;
+    if (rf == 0.f) {
+      run = gt;                       // first time the class is seen (ttda:1760-1762)
+      new_flag = 1.f;
+    } else {
+      run = omr * run + rho * gt;     // ttda:1764
+    }
+  }
+  run_proto[(size_t)c * CH + ch] = run;
+  // flags are written by a second tiny kernel (below) so that no block reads a flag another block already updated
+}
+
+__global__ void proto_flags_kernel(const int32_t* __restrict__ counts, int C, float* __restrict__ inst_flag,
+                                   float* __restrict__ run_flag, int32_t* __restrict__ state_flag, float rho) {
+  const int c = threadIdx.x;
+  const bool seeded = *state_flag != 0;
+  __syncthreads();
+  if (c < C) {
+    const int n_pl = counts[c], n_gt = counts[C + c];
+    inst_flag[c] = n_pl > 0 ? 1.f : 0.f;
+    if (!seeded)
+      run_flag[c] = n_pl > 0 ? 1.f : 0.f;
+    else if (n_gt > 0 && rho != 0.f)
+      run_flag[c] = 1.f;
+  }
+  if (c == 0) *state_flag = 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// prototype-distance classifier x2 + blend + softmax fusion (ttda:1707-1709, 1712-1734, 1644)
+// Block = 32 pixels.  Channel loop in chunks of 64: the pixel tile (fp32, pitch 65) and the 2C
+// prototypes (padded to 40 rows, stored [ch][8 groups][8] so a thread reads its 5 classes with one
+// b128 + one b32 broadcast read) are staged in LDS; thread (pix = t&31, grp = t>>5) accumulates the
+// squared distance to its 5 prototypes directly: sum (p - f)^2 in fp32, no ||f||^2-2fp+||p||^2
+// expansion (absolute error in d would be relative error in exp(-d)).
+// ---------------------------------------------------------------------------------------------
+constexpr int PCF_PIX = 32;
+constexpr int PCF_SLOTS = 40;
+
+__global__ __launch_bounds__(256) void proto_classify_fuse_kernel(const unsigned short* __restrict__ feat,
+                                                                  const float* __restrict__ logits,
+                                                                  const float* __restrict__ inst_proto,
+                                                                  const float* __restrict__ inst_flag,
+                                                                  const float* __restrict__ run_proto,
+                                                                  const float* __restrict__ run_flag, float* __restrict__ out,
+                                                                  int64_t P, int C, int hw, int CH, float tau, float pl, float pl1,
+                                                                  float fl, float fl1) {
+  __shared__ float sf[PCF_PIX][65];
+  __shared__ __attribute__((aligned(16))) float spr[64][8][8];   // [ch][grp][5 used of 8]
+  __shared__ float sd[PCF_PIX][PCF_SLOTS + 1];
+  const int tid = threadIdx.x, pix = tid & 31, grp = tid >> 5;
+  const int64_t p0 = (int64_t)blockIdx.x * PCF_PIX;
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int ch0 = 0; ch0 < CH; ch0 += 64) {
+    __syncthreads();
+    {  // feature tile: 32 px x 64 ch = 256 octets, one per thread
+      const int r = tid >> 3, o = tid & 7;
+      float f[8];
+      if (p0 + r < P) {
+        unpack_bf16x8(*reinterpret_cast<const u32x4*>(feat + (size_t)(p0 + r) * CH + ch0 + o * 8), f);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sf[r][o * 8 + i] = f[i];
+    }
+    for (int e = tid; e < PCF_SLOTS * 64; e += 256) {   // prototypes: slot k = instance class k (k < C), running class k-C
+      const int ch = e & 63, k = e >> 6;
+      float v = 0.f;
+      if (k < C)
+        v = inst_proto[(size_t)k * CH + ch0 + ch];
+      else if (k < 2 * C)
+        v = run_proto[(size_t)(k - C) * CH + ch0 + ch];
+      spr[ch][k / 5][k % 5] = v;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int ch = 0; ch < 64; ++ch) {
+      const float f = sf[pix][ch];
+      const f32x4 q = *reinterpret_cast<const f32x4*>(&spr[ch][grp][0]);
+      const float q4 = spr[ch][grp][4];
+      float d;
+      d = q[0] - f; acc[0] = fmaf(d, d, acc[0]);
+      d = q[1] - f; acc[1] = fmaf(d, d, acc[1]);
+      d = q[2] - f; acc[2] = fmaf(d, d, acc[2]);
+      d = q[3] - f; acc[3] = fmaf(d, d, acc[3]);
+      d = q4 - f;   acc[4] = fmaf(d, d, acc[4]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) sd[pix][grp * 5 + i] = acc[i];
+  __syncthreads();
+  if (tid < PCF_PIX && p0 + tid < P) {
+    const int64_t p = p0 + tid;
+    const int64_t b = p / hw, px = p - b * hw;
+    float wi[DIGA_NUM_CLASSES_MAX], wr[DIGA_NUM_CLASSES_MAX], l[DIGA_NUM_CLASSES_MAX];
+    float si = 0.f, sr = 0.f, mx = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+      wi[c] = expf(-sqrtf(sd[tid][c]) / tau) * inst_flag[c];
+      wr[c] = expf(-sqrtf(sd[tid][C + c]) / tau) * run_flag[c];
+      si += wi[c];
+      sr += wr[c];
+      l[c] = logits[((size_t)b * C + c) * hw + px];
+      mx = fmaxf(mx, l[c]);
+    }
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) {
+      l[c] = expf(l[c] - mx);
+      se += l[c];
+    }
+    for (int c = 0; c < C; ++c) {
+      const float multi = pl * (wr[c] / sr) + pl1 * (wi[c] / si);     // ttda:1709 (0/0 -> NaN kept)
+      out[((size_t)b * C + c) * hw + px] = multi * fl + (l[c] / se) * fl1;   // ttda:1644
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int diga_head_finish_pseudo_label(const float* partials, int splitk, int cpad, const float* bias_sum,
+                                             const float* logits_in, float* logits_out, int32_t* labels, int B, int C, int hw,
+                                             float threshold, void* stream) {
+  DIGA_CHECK_ARG((partials != nullptr) != (logits_in != nullptr), "diga_head_finish_pseudo_label: give partials or logits_in");
+  DIGA_CHECK_ARG(labels && B > 0 && hw > 0 && C > 0 && C <= DIGA_NUM_CLASSES_MAX, "diga_head_finish_pseudo_label: bad argument");
+  DIGA_CHECK_ARG(!partials || (bias_sum && splitk >= 1 && cpad >= C), "diga_head_finish_pseudo_label: bad partials description");
+  const int64_t P = (int64_t)B * hw;
+  hipLaunchKernelGGL(head_finish_pl_kernel, dim3(cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, partials, splitk, cpad,
+                     bias_sum, logits_in, logits_out, labels, P, C, hw, threshold);
+  DIGA_CHECK_LAUNCH("diga_head_finish_pseudo_label");
+  return DIGA_OK;
+}
+
+extern "C" int diga_nearest_down_labels(const void* y, int y_is_i64, int32_t* out, int B, int H, int W, int h, int w,
+                                        void* stream) {
+  DIGA_CHECK_ARG(y && out && B > 0 && H > 0 && W > 0 && h > 0 && w > 0, "diga_nearest_down_labels: bad argument");
+  const int64_t n = (int64_t)B * h * w;
+  if (y_is_i64)
+    hipLaunchKernelGGL(nearest_down_kernel<int64_t>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const int64_t*)y, out,
+                       B, H, W, h, w);
+  else
+    hipLaunchKernelGGL(nearest_down_kernel<int32_t>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const int32_t*)y, out,
+                       B, H, W, h, w);
+  DIGA_CHECK_LAUNCH("diga_nearest_down_labels");
+  return DIGA_OK;
+}
+
+namespace {
+struct PoolPlan {
+  int CS, JC;
+  int64_t idx_bytes, partial_bytes;
+};
+PoolPlan pool_plan(int nsets, int64_t P, int C, int CH) {
+  PoolPlan pp;
+  pp.CS = (int)((P + 63) / 64);
+  if (pp.CS < 64) pp.CS = 64;
+  pp.JC = (int)((P + pp.CS - 1) / pp.CS);
+  pp.idx_bytes = (((int64_t)nsets * C * P * 4) + 255) / 256 * 256;
+  pp.partial_bytes = (int64_t)nsets * C * pp.JC * CH * 4;
+  return pp;
+}
+}  // namespace
+
+extern "C" int64_t diga_proto_pool_work_bytes(int nsets, int64_t P, int C, int CH) {
+  if (nsets < 1 || nsets > 2 || P <= 0 || C <= 0 || CH <= 0) return DIGA_EINVAL;
+  const PoolPlan pp = pool_plan(nsets, P, C, CH);
+  return pp.idx_bytes + pp.partial_bytes;
+}
+
+extern "C" int diga_proto_pool(const void* feat, const int32_t* labels, int nsets, int64_t P, int C, int CH, void* work,
+                               float* sums, int32_t* counts, void* stream) {
+  DIGA_CHECK_ARG(feat && labels && work && sums && counts, "diga_proto_pool: NULL pointer");
+  DIGA_CHECK_ARG(nsets >= 1 && nsets <= 2 && P > 0 && P < (1ll << 31) && C > 0 && C <= DIGA_NUM_CLASSES_MAX && CH > 0 && CH % 8 == 0,
+                 "diga_proto_pool: bad sizes");
+  const PoolPlan pp = pool_plan(nsets, P, C, CH);
+  int32_t* idx = (int32_t*)work;
+  float* partial = (float*)((char*)work + pp.idx_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(proto_index_kernel, dim3(C, nsets), dim3(64), 0, st, labels, P, C, idx, counts);
+  hipLaunchKernelGGL(proto_pool_kernel, dim3(pp.JC, C, nsets), dim3(256), 0, st, (const unsigned short*)feat, idx, counts, P, C, CH,
+                     pp.CS, pp.JC, partial);
+  hipLaunchKernelGGL(proto_reduce_kernel, dim3(cdiv(CH, 256), nsets * C), dim3(256), 0, st, partial, counts, C, CH, pp.CS, pp.JC,
+                     sums);
+  DIGA_CHECK_LAUNCH("diga_proto_pool");
+  return DIGA_OK;
+}
+
+extern "C" int diga_proto_update(const float* sums, const int32_t* counts, int C, int CH, float* inst_proto, float* inst_flag,
+                                 float* run_proto, float* run_flag, int32_t* state_flag, float one_minus_rho, float rho,
+                                 void* stream) {
+  DIGA_CHECK_ARG(sums && counts && inst_proto && inst_flag && run_proto && run_flag && state_flag, "diga_proto_update: NULL pointer");
+  DIGA_CHECK_ARG(C > 0 && C <= DIGA_NUM_CLASSES_MAX && CH > 0, "diga_proto_update: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(proto_update_kernel, dim3(cdiv(CH, 256), C), dim3(256), 0, st, sums, counts, C, CH, inst_proto, inst_flag,
+                     run_proto, run_flag, state_flag, one_minus_rho, rho);
+  hipLaunchKernelGGL(proto_flags_kernel, dim3(1), dim3(64), 0, st, counts, C, inst_flag, run_flag, state_flag, rho);
+  DIGA_CHECK_LAUNCH("diga_proto_update");
+  return DIGA_OK;
+}
+
+extern "C" int diga_proto_classify_fuse(const void* feat, const float* logits, const float* inst_proto, const float* inst_flag,
+                                        const float* run_proto, const float* run_flag, float* out, int B, int C, int hw, int CH,
+                                        float tau, float pl, float pl1, float fl, float fl1, void* stream) {
+  DIGA_CHECK_ARG(feat && logits && inst_proto && inst_flag && run_proto && run_flag && out, "diga_proto_classify_fuse: NULL pointer");
+  DIGA_CHECK_ARG(B > 0 && hw > 0 && C > 0 && 2 * C <= PCF_SLOTS && CH > 0 && CH % 64 == 0, "diga_proto_classify_fuse: bad sizes (C <= 20, CH %% 64 == 0)");
+  const int64_t P = (int64_t)B * hw;
+  hipLaunchKernelGGL(proto_classify_fuse_kernel, dim3(cdiv(P, PCF_PIX)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)feat, logits, inst_proto, inst_flag, run_proto, run_flag, out, P, C, hw, CH, tau, pl,
+                     pl1, fl, fl1);
+  DIGA_CHECK_LAUNCH("diga_proto_classify_fuse");
+  return DIGA_OK;
+}

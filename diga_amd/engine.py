@@ -1,0 +1,371 @@
+"""Host-side execution plan for the DIGA forward path on one MI355X.
+
+PyTorch is used for device memory, streams, HIP-graph capture and (optionally) torch.distributed;
+every arithmetic step is a call into libdiga_hip.so (include/diga_hip.h).  The plan mirrors the
+reference's call stack:
+
+    net(x, feat=True)            adaptseg.py:177-188     -> Engine.forward_feat
+    multi_proto_label + fusion   ttda_module.py:1678-1710, 1644   -> Engine.sam_fuse
+    step(): upsample + metric    ttda_module.py:1610, 158-173     -> Engine.tail
+
+Data layout in HBM: activations NHWC bf16, weights [Cout][tap][Cin] bf16, statistics / prototypes /
+logits / probabilities fp32, labels int32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, call
+
+LAYERS = (3, 4, 23, 3)
+PLANES = (64, 128, 256, 512)
+STRIDES = (1, 2, 1, 1)
+DILATIONS = (1, 1, 2, 4)
+HEAD_DILS = (6, 12)          # only the first two head branches ever run (adaptseg.py:119-122)
+FEAT_CH = 2048
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pool_out(L):
+    """MaxPool2d(3, 2, 1, ceil_mode=True) output size (adaptseg.py:139)."""
+    o = L // 2 + 1
+    if (o - 1) * 2 >= L + 1:
+        o -= 1
+    return o
+
+
+def feature_grid(H, W):
+    h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1          # conv1 7x7 s2 p3
+    h2, w2 = pool_out(h1), pool_out(w1)                   # maxpool
+    h3, w3 = (h2 - 1) // 2 + 1, (w2 - 1) // 2 + 1         # layer2 stride-2 1x1 (no padding)
+    return (h1, w1), (h2, w2), (h3, w3)
+
+
+def pack_conv_weight(w: torch.Tensor, cout_pad: int | None = None) -> torch.Tensor:
+    """[Cout,Cin,kh,kw] fp32 -> [cout_pad][kh*kw*Cin] bf16 (tap-major, channel-minor), zero-padded rows."""
+    co, ci, kh, kw = w.shape
+    out = w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+    if cout_pad is not None and cout_pad > co:
+        out = torch.cat([out, out.new_zeros(cout_pad - co, out.shape[1])], 0)
+    return out.to(torch.bfloat16).contiguous()
+
+
+@dataclass
+class BNP:
+    """Device-resident parameters of one DAM BN layer."""
+    running_mean: torch.Tensor
+    running_var: torch.Tensor
+    weight: torch.Tensor
+    bias: torch.Tensor
+    C: int
+    off: int = 0        # offset of this layer's scale/shift in the shared buffers
+
+
+class NetWeights:
+    """Packs a reference-layout AdaptSegNet state dict for the kernels (one-off, at load time)."""
+
+    def __init__(self, sd: dict, device, num_classes: int = 19):
+        def dev(v, dt=torch.float32):
+            if isinstance(v, np.ndarray):
+                v = torch.from_numpy(np.ascontiguousarray(v))
+            return v.detach().to(device=device, dtype=dt).contiguous()
+
+        self.device = device
+        self.num_classes = num_classes
+        self.stem_w = dev(sd["conv1.weight"]).reshape(64, 147).contiguous()
+        self.conv = {}
+        self.bn = {}
+        off = 0
+
+        def add_bn(name):
+            nonlocal off
+            b = BNP(dev(sd[name + ".running_mean"]), dev(sd[name + ".running_var"]), dev(sd[name + ".weight"]),
+                    dev(sd[name + ".bias"]), int(sd[name + ".weight"].shape[0]), off)
+            off += b.C
+            self.bn[name] = b
+
+        add_bn("bn1")
+        for li, nb in enumerate(LAYERS, start=1):
+            for b in range(nb):
+                pre = f"layer{li}.{b}"
+                for k in ("conv1", "conv2", "conv3"):
+                    self.conv[f"{pre}.{k}"] = pack_conv_weight(dev(sd[f"{pre}.{k}.weight"]))
+                for k in ("bn1", "bn2", "bn3"):
+                    add_bn(f"{pre}.{k}")
+                if b == 0:
+                    self.conv[f"{pre}.downsample.0"] = pack_conv_weight(dev(sd[f"{pre}.downsample.0.weight"]))
+                    add_bn(f"{pre}.downsample.1")
+        self.bn_channels = off
+        # heads: the two executed branches (dil 6 + dil 12, adaptseg.py:119-122) fused into one 18-tap conv,
+        # Cout padded 19 -> 32.  layer6 = main head (on layer4), layer5 = aux head (on layer3, only for net(x)).
+        self.head_cpad = 32
+
+        def pack_head(prefix):
+            w0, w1 = dev(sd[prefix + ".conv2d_list.0.weight"]), dev(sd[prefix + ".conv2d_list.1.weight"])
+            hw = torch.cat([w0.permute(0, 2, 3, 1).reshape(num_classes, -1), w1.permute(0, 2, 3, 1).reshape(num_classes, -1)], 1)
+            hw = torch.cat([hw, hw.new_zeros(self.head_cpad - num_classes, hw.shape[1])], 0).to(torch.bfloat16).contiguous()
+            return hw, (dev(sd[prefix + ".conv2d_list.0.bias"]) + dev(sd[prefix + ".conv2d_list.1.bias"])).contiguous()
+
+        self.head_w, self.head_bias = pack_head("layer6")
+        self.aux_w, self.aux_bias = pack_head("layer5") if "layer5.conv2d_list.0.weight" in sd else (None, None)
+
+
+class Engine:
+    """Static plan + buffers for one input shape (B, H, W) on the current device."""
+
+    def __init__(self, weights: NetWeights, B: int, H: int, W: int, bn_lambda: float = 0.8, group=None,
+                 head_splitk: int = 4, confidence_threshold: float = 0.9):
+        _lib.load()
+        self.w = weights
+        self.dev = weights.device
+        self.B, self.H, self.W = B, H, W
+        self.C = weights.num_classes
+        self.lam = float(np.float32(bn_lambda))
+        self.group = group
+        if group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        (self.h1, self.w1), (self.h2, self.w2), (self.h3, self.w3) = feature_grid(H, W)
+        self.h, self.wd = self.h3, self.w3
+        self.hw = self.h * self.wd
+        self.P = B * self.hw
+        self.head_splitk = head_splitk
+        self.threshold = float(np.float32(confidence_threshold))
+        dev = self.dev
+        bf, f32, i32 = torch.bfloat16, torch.float32, torch.int32
+
+        def buf(n, dt):
+            return torch.empty(int(n), dtype=dt, device=dev)
+
+        n1 = B * self.h1 * self.w1
+        n2 = B * self.h2 * self.w2
+        n3 = B * self.h3 * self.w3
+        self.stem_raw = buf(n1 * 64, bf)
+        big = max(n2 * 256, n3 * 2048)            # largest block input / output
+        self.xa, self.xb = buf(big, bf), buf(big, bf)
+        mid = max(n2 * 64, n2 * 128, n3 * 512)    # conv1 / conv2 outputs (layer2.0.conv1 is already strided)
+        self.raw1, self.act1, self.raw2, self.act2 = buf(mid, bf), buf(mid, bf), buf(mid, bf), buf(mid, bf)
+        self.raw3, self.rawd = buf(big, bf), buf(big, bf)
+        self.scale = buf(weights.bn_channels, f32)
+        self.shift = buf(weights.bn_channels, f32)
+        # statistics slab shared by all layers (each is consumed by its finalize before the next conv runs)
+        self.stem_tiles = call("diga_stem_conv7x7s2", None, None, None, None, None, B, H, W, 0, None)
+        self.slab = buf(max(self.stem_tiles * 4 * 64, (n2 // 64 + 2) * 4 * 256, (n3 // 64 + 2) * 4 * 2048), f32)
+        self.sums = buf(4 * 2048, f32)
+        # head / SAM
+        self.head_part = buf(head_splitk * self.P * weights.head_cpad, f32)
+        self.logits = torch.empty(B, self.C, self.h, self.wd, dtype=f32, device=dev)
+        self.labels = buf(2 * self.P, i32)                       # [pseudo | ground truth]
+        self.pool_work = torch.empty(int(_lib.load().diga_proto_pool_work_bytes(2, self.P, self.C, FEAT_CH)),
+                                     dtype=torch.uint8, device=dev)
+        self.pool_sums = torch.zeros(2 * self.C * FEAT_CH, dtype=f32, device=dev)
+        self.pool_counts = torch.zeros(2 * self.C, dtype=i32, device=dev)
+        self.inst_proto = torch.zeros(self.C, FEAT_CH, dtype=f32, device=dev)
+        self.inst_flag = torch.zeros(self.C, dtype=f32, device=dev)
+        self.run_proto = torch.zeros(self.C, FEAT_CH, dtype=f32, device=dev)
+        self.run_flag = torch.zeros(self.C, dtype=f32, device=dev)
+        self.state_flag = torch.zeros(1, dtype=i32, device=dev)
+        self.probs = torch.empty(B, self.C, self.h, self.wd, dtype=f32, device=dev)
+        self.pred = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
+        self.hist = torch.zeros(self.C * self.C, dtype=torch.int64, device=dev)
+        self.feat = None          # bf16 NHWC view of the layer4 output, set by forward_feat
+        self.conv_flops = 0       # 2*MAC of the executed convs (filled by the first forward_feat)
+        self.taps = None          # optional dict: name -> (tensor, shape) of intermediate activations (tests)
+
+    # ------------------------------------------------------------------ helpers
+    def _groups(self, rows_per_sample):
+        """(split_row, n_a, n_b) of the reference's half_first rule (ttda:313-320) for the *global* batch."""
+        gb = self.B * self.world
+        if gb == 1:
+            return self.B * rows_per_sample, float(rows_per_sample), 0.0
+        split = rows_per_sample if self.rank == 0 else 0
+        return split, float(rows_per_sample), float((gb - 1) * rows_per_sample)
+
+    def _finalize(self, bn: BNP, ntiles, rows_per_sample):
+        _, n_a, n_b = self._groups(rows_per_sample)
+        sc, sh = self.scale[bn.off:bn.off + bn.C], self.shift[bn.off:bn.off + bn.C]
+        slab, nt = self.slab, ntiles
+        if self.world > 1:
+            import torch.distributed as dist
+            sums = self.sums[:4 * bn.C]
+            call("diga_bn_reduce_slab", _p(self.slab), ntiles, bn.C, _p(sums), _stream())
+            dist.all_reduce(sums, group=self.group)
+            slab, nt = sums, 1
+        call("diga_bn_finalize", _p(slab), nt, bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var), _p(bn.weight),
+             _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
+        return sc, sh
+
+    def _conv(self, name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn: BNP | None):
+        d = ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = self.B, Hin, Win, Cin, Ho, Wo, Cout
+        d.stride = stride
+        if k3:
+            d.ntaps = 9
+            for t in range(9):
+                d.dy[t], d.dx[t] = (t // 3 - 1) * dil, (t % 3 - 1) * dil
+        else:
+            d.ntaps = 1
+        d.cout_pad = Cout
+        d.split_row = self._groups(Ho * Wo)[0]
+        d.splitk, d.out_f32, d.tile = 1, 0, 0
+        nt = call("diga_conv_num_mtiles", C.byref(d))
+        call("diga_conv_igemm_bf16", C.byref(d), _p(x), _p(self.w.conv[name]), _p(out), _p(self.slab), _p(bn.running_mean),
+             _stream())
+        self.conv_flops += 2 * self.B * Ho * Wo * Cout * Cin * d.ntaps
+        return nt
+
+    def _tap(self, name, t, shape):
+        if self.taps is not None:
+            self.taps[name] = (t[:int(np.prod(shape))].clone(), shape)
+
+    # ------------------------------------------------------------------ net(x, feat=True)
+    def forward_feat(self, x: torch.Tensor, want_aux: bool = False):
+        """x: fp32 NCHW [B,3,H,W] on the device.  Leaves the layer4 features in self.feat (bf16 [P,2048]),
+        the logits in self.logits (fp32 NCHW) and the pseudo labels in self.labels[:P].  adaptseg.py:177-188.
+        want_aux also runs the aux head (layer5 on the layer3 output, adaptseg.py:190) into self.aux_logits."""
+        assert x.shape == (self.B, 3, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
+        w, B = self.w, self.B
+        self.conv_flops = 2 * B * self.h1 * self.w1 * 64 * 147
+        bn = w.bn["bn1"]
+        split, _, _ = self._groups(self.h1 * self.w1)
+        call("diga_stem_conv7x7s2", _p(x), _p(w.stem_w), _p(self.stem_raw), _p(self.slab), _p(bn.running_mean), B, self.H,
+             self.W, split, _stream())
+        ntiles = self.stem_tiles
+        self._tap("conv1", self.stem_raw, (B, self.h1, self.w1, 64))
+        sc, sh = self._finalize(bn, ntiles, self.h1 * self.w1)
+        cur, nxt = self.xa, self.xb
+        call("diga_bn_relu_maxpool", _p(self.stem_raw), _p(sc), _p(sh), _p(cur), B, self.h1, self.w1, 64, self.h2, self.w2,
+             _stream())
+        self._tap("maxpool", cur, (B, self.h2, self.w2, 64))
+        Hc, Wc, Cc = self.h2, self.w2, 64
+        for li, (nb, pl, st, dil) in enumerate(zip(LAYERS, PLANES, STRIDES, DILATIONS), start=1):
+            for b in range(nb):
+                pre = f"layer{li}.{b}"
+                s = st if b == 0 else 1
+                Ho, Wo = (Hc - 1) // s + 1, (Wc - 1) // s + 1
+                M = B * Ho * Wo
+                rows = Ho * Wo
+                # conv1 (1x1, carries the stride) -> bn1 -> relu
+                bn1 = w.bn[pre + ".bn1"]
+                nt = self._conv(pre + ".conv1", cur, self.raw1, Hc, Wc, Cc, Ho, Wo, pl, s, 1, False, bn1)
+                self._tap(pre + ".conv1", self.raw1, (B, Ho, Wo, pl))
+                sc, sh = self._finalize(bn1, nt, rows)
+                call("diga_bn_apply", _p(self.raw1), _p(sc), _p(sh), None, None, None, _p(self.act1), M, pl, 1, _stream())
+                self._tap(pre + ".act1", self.act1, (B, Ho, Wo, pl))
+                # conv2 (3x3 dilated, pad = dilation) -> bn2 -> relu
+                bn2 = w.bn[pre + ".bn2"]
+                nt = self._conv(pre + ".conv2", self.act1, self.raw2, Ho, Wo, pl, Ho, Wo, pl, 1, dil, True, bn2)
+                self._tap(pre + ".conv2", self.raw2, (B, Ho, Wo, pl))
+                sc, sh = self._finalize(bn2, nt, rows)
+                call("diga_bn_apply", _p(self.raw2), _p(sc), _p(sh), None, None, None, _p(self.act2), M, pl, 1, _stream())
+                self._tap(pre + ".act2", self.act2, (B, Ho, Wo, pl))
+                # conv3 (1x1) -> bn3
+                bn3 = w.bn[pre + ".bn3"]
+                nt = self._conv(pre + ".conv3", self.act2, self.raw3, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)
+                self._tap(pre + ".conv3", self.raw3, (B, Ho, Wo, pl * 4))
+                sc3, sh3 = self._finalize(bn3, nt, rows)
+                if b == 0:    # downsample branch: 1x1 (stride) + bn on the block input
+                    bnd = w.bn[pre + ".downsample.1"]
+                    nt = self._conv(pre + ".downsample.0", cur, self.rawd, Hc, Wc, Cc, Ho, Wo, pl * 4, s, 1, False, bnd)
+                    self._tap(pre + ".downsample.0", self.rawd, (B, Ho, Wo, pl * 4))
+                    scd, shd = self._finalize(bnd, nt, rows)
+                    call("diga_bn_apply", _p(self.raw3), _p(sc3), _p(sh3), _p(self.rawd), _p(scd), _p(shd), _p(nxt), M, pl * 4, 1,
+                         _stream())
+                else:
+                    call("diga_bn_apply", _p(self.raw3), _p(sc3), _p(sh3), _p(cur), None, None, _p(nxt), M, pl * 4, 1, _stream())
+                cur, nxt = nxt, cur
+                Hc, Wc, Cc = Ho, Wo, pl * 4
+                self._tap(pre, cur, (B, Ho, Wo, Cc))
+            if li == 3 and want_aux:
+                self.aux_logits = torch.empty_like(self.logits)
+                self._head(cur[:self.P * 1024], 1024, self.w.aux_w, self.w.aux_bias, self.aux_logits, self.labels[self.P:])
+        assert (Hc, Wc, Cc) == (self.h, self.wd, FEAT_CH)
+        self.feat = cur[:self.P * FEAT_CH]
+        self._head(self.feat, FEAT_CH, self.w.head_w, self.w.head_bias, self.logits, self.labels)
+        return self.feat, self.logits
+
+    def _head(self, feat, cin, hw, hbias, logits, labels):
+        d = ConvDesc()
+        d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = self.B, self.h, self.wd, cin, self.h, self.wd, self.C
+        d.stride, d.ntaps = 1, 18
+        for br, dil in enumerate(HEAD_DILS):
+            for t in range(9):
+                d.dy[br * 9 + t], d.dx[br * 9 + t] = (t // 3 - 1) * dil, (t % 3 - 1) * dil
+        d.cout_pad = self.w.head_cpad
+        d.split_row = self.P
+        d.splitk, d.out_f32, d.tile = self.head_splitk, 1, 5
+        call("diga_conv_igemm_bf16", C.byref(d), _p(feat), _p(hw), _p(self.head_part), None, None, _stream())
+        self.conv_flops += 2 * self.P * self.C * cin * 18
+        # split-K partials + bias -> logits (NCHW fp32) and the confidence-thresholded pseudo labels (ttda:1662-1676)
+        call("diga_head_finish_pseudo_label", _p(self.head_part), self.head_splitk, self.w.head_cpad, _p(hbias), None,
+             _p(logits), _p(labels), self.B, self.C, self.hw, self.threshold, _stream())
+
+    # ------------------------------------------------------------------ SAM + fusion
+    def sam_fuse(self, y: torch.Tensor, cfg):
+        """multi_proto_label + fusion (ttda:1678-1710, 1644) on the current features/logits.
+        y: [B,H,W] int64/int32 ground truth on the device (255 = ignore)."""
+        B, Cn = self.B, self.C
+        assert y.shape[0] == B and y.dtype in (torch.int64, torch.int32) and y.is_contiguous()
+        assert float(np.float32(cfg["confidence_threshold"])) == self.threshold
+        call("diga_nearest_down_labels", _p(y), int(y.dtype == torch.int64), _p(self.labels[self.P:]), B, y.shape[1], y.shape[2],
+             self.h, self.wd, _stream())
+        call("diga_proto_pool", _p(self.feat), _p(self.labels), 2, self.P, Cn, FEAT_CH, _p(self.pool_work), _p(self.pool_sums),
+             _p(self.pool_counts), _stream())
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.pool_sums, group=self.group)
+            dist.all_reduce(self.pool_counts, group=self.group)
+        rho = float(cfg["proto_rho"])
+        call("diga_proto_update", _p(self.pool_sums), _p(self.pool_counts), Cn, FEAT_CH, _p(self.inst_proto), _p(self.inst_flag),
+             _p(self.run_proto), _p(self.run_flag), _p(self.state_flag), float(np.float32(1 - rho)), float(np.float32(rho)),
+             _stream())
+        pl, fl = float(cfg["proto_lambda"]), float(cfg["fusion_lambda"])
+        call("diga_proto_classify_fuse", _p(self.feat), _p(self.logits), _p(self.inst_proto), _p(self.inst_flag),
+             _p(self.run_proto), _p(self.run_flag), _p(self.probs), B, Cn, self.hw, FEAT_CH, 1.0, float(np.float32(pl)),
+             float(np.float32(1 - pl)), float(np.float32(fl)), float(np.float32(1 - fl)), _stream())
+        return self.probs
+
+    def forward_and_adapt(self, x, y, cfg):
+        self.forward_feat(x)
+        return self.sam_fuse(y, cfg)
+
+    # ------------------------------------------------------------------ tail
+    def tail(self, y: torch.Tensor, probs_up: torch.Tensor | None = None):
+        """Upsample + argmax + confusion matrix (ttda:1610, 158-173). Accumulates into self.hist."""
+        H, W = y.shape[1], y.shape[2]
+        if self.pred.shape != y.shape:
+            self.pred = torch.empty(y.shape, dtype=torch.uint8, device=self.dev)
+        call("diga_upsample_argmax_hist", _p(self.probs), _p(y), int(y.dtype == torch.int64), _p(self.pred), _p(self.hist),
+             _p(probs_up), self.B, self.C, self.h, self.wd, H, W, _stream())
+        return self.pred
+
+    def reset_state(self):
+        self.state_flag.zero_()
+        self.run_proto.zero_()
+        self.run_flag.zero_()
+        self.hist.zero_()
+
+    # ------------------------------------------------------------------ layout helpers (API / tests)
+    def nhwc_to_nchw(self, t: torch.Tensor, shape):
+        B, H, W, Cc = shape
+        out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=self.dev)
+        call("diga_nhwc_bf16_to_nchw_f32", _p(t), _p(out), B, H * W, Cc, _stream())
+        return out
+
+    def feat_nchw(self):
+        return self.nhwc_to_nchw(self.feat, (self.B, self.h, self.wd, FEAT_CH))

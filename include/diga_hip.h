@@ -1,0 +1,170 @@
+/*
+ * diga_hip.h -- C-ABI of libdiga_hip.so: the MI355X (gfx950) kernels behind DIGA's backward-free
+ * test-time-adaptation forward path.
+ *
+ * The reference (Waybaba/DIGA) is 100 % Python: it has no FFI/operator layer, its "kernels" are
+ * ATen ops reached from eager PyTorch.  Each entry point below therefore cites the reference
+ * *Python call site* it replaces ("ttda" = src/models/ttda_module.py, "adaptseg" =
+ * src/models/components/adaptseg.py).  The host-side mirror of the reference's class API
+ * (diga_amd/ttda_module.py: DIGA, DeepLabv2AdaptSeg, SIFABatchNorm2dTrainable, SegmentationMetric)
+ * binds these with ctypes -- see INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer on the current HIP device unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it;
+ *   - no entry point allocates, frees or synchronises (safe under stream capture);
+ *   - return value: 0 on success, negative DIGA_E* on error (never throws);
+ *     diga_last_error_string() describes the last error of the calling thread;
+ *   - activations are NHWC ("pixels x channels") bf16 (raw uint16_t bit patterns), statistics,
+ *     prototypes, logits and probabilities are fp32, labels are int32 internally.
+ */
+#ifndef DIGA_HIP_H
+#define DIGA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIGA_OK 0
+#define DIGA_EINVAL (-1)   /* bad argument / unsupported shape */
+#define DIGA_ELAUNCH (-2)  /* HIP launch error */
+
+#define DIGA_MAX_TAPS 18
+#define DIGA_NUM_CLASSES_MAX 32
+
+int diga_version(void);
+const char* diga_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolutions (adaptseg:63-74 Bottleneck convs, adaptseg:111,119-121 head; nn.Conv2d call sites
+ * adaptseg:85,89,93,97,178).  Implicit GEMM on bf16 MFMA with fp32 accumulation:
+ *   out[m, co] = sum_{tap, ci} in[n, oh*stride+dy[tap], ow*stride+dx[tap], ci] * wgt[co, tap, ci]
+ * with m = (n, oh, ow) flattened; out-of-image taps read as zero (== zero padding).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t B, H, W, Cin;        /* input  NHWC bf16; Cin % 64 == 0 */
+  int32_t Ho, Wo, Cout;        /* output NHWC; Cout % 8 == 0 for bf16 output */
+  int32_t stride;              /* 1 or 2 (stride sits on the first 1x1 of a block, adaptseg:63) */
+  int32_t ntaps;               /* 1 (1x1), 9 (3x3 dilated) or 18 (fused 2-branch head) */
+  int16_t dy[DIGA_MAX_TAPS];   /* tap offsets in input pixels, e.g. (kh-1)*dilation */
+  int16_t dx[DIGA_MAX_TAPS];
+  int32_t cout_pad;            /* rows of wgt (>= Cout, multiple of the N tile); padding rows are zero */
+  int32_t split_row;           /* rows m < split_row -> statistics group A, the rest -> group B
+                                  (the reference's half_first rule, ttda:313-320); = M for one group */
+  int32_t splitk;              /* >= 1; > 1 only with out_f32 */
+  int32_t out_f32;             /* 0: out = bf16 [M][Cout];  1: out = fp32 [splitk][M][cout_pad] partials */
+  int32_t tile;                /* 0 = auto; else tile-config id (see diga_conv_tile_info) */
+} diga_conv_desc;
+
+/* Number of M tiles the kernel will use for `desc` (= rows of the statistics slab). */
+int diga_conv_num_mtiles(const diga_conv_desc* desc);
+
+/* in: bf16 NHWC; wgt: bf16 [cout_pad][ntaps*Cin]; out: see desc.out_f32;
+ * stat_slab: NULL, or fp32 [num_mtiles][2 groups][2 (sum, sumsq)][Cout] of *shifted* values
+ * (x - stat_shift[c]) taken from the fp32 accumulators; stat_shift: fp32 [Cout] (the source
+ * running_mean: the shifted-data variance algorithm stays accurate when mean >> std). */
+int diga_conv_igemm_bf16(const diga_conv_desc* desc, const void* in, const void* wgt, void* out,
+                         float* stat_slab, const float* stat_shift, void* stream);
+
+/* Stem (adaptseg:133,178): 7x7 stride 2 pad 3, 3 -> 64, fp32 NCHW input [B,3,H,W] -> raw bf16 NHWC
+ * [B,Ho,Wo,64] + statistics slab [num_tiles][2][2][64] (same format as above).
+ * wgt: fp32 [64][3][7][7] (the reference layout).  Returns the number of slab tiles when x == NULL. */
+int diga_stem_conv7x7s2(const float* x, const float* wgt, void* out, float* stat_slab,
+                        const float* stat_shift, int B, int H, int W, int split_row, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DAM batch norm (SIFABatchNorm2d.forward eval branch, ttda:299-345).
+ * ------------------------------------------------------------------------------------------ */
+/* Reduce a statistics slab in fixed tile order (deterministic) and produce the per-channel affine
+ *   mean_g = K + S1_g/n_g,  var_g = S2_g/n_g - (S1_g/n_g)^2            (g = A, B; biased var)
+ *   mean_cur = n_b > 0 ? (mean_A + mean_B)/2 : mean_A   (same for var)   ttda:315-320
+ *   mean = lam*running_mean + (1-lam)*mean_cur, var likewise (1-lam in fp32)   ttda:335-336
+ *   scale = weight / sqrt(var + eps),  shift = bias - mean*scale        ttda:341-343
+ * slab: fp32 [ntiles][2][2][C]; n_a / n_b: element counts of the two groups (global counts when the
+ * slab holds all-reduced sums).  scale/shift: fp32 [C]. */
+int diga_bn_finalize(const float* slab, int ntiles, int C, double n_a, double n_b,
+                     const float* running_mean, const float* running_var, const float* weight,
+                     const float* bias, float lam, float eps, float* scale, float* shift, void* stream);
+
+/* Sum a slab over its tiles only: sums[2][2][C] fp32 (what the multi-GPU path all-reduces). */
+int diga_bn_reduce_slab(const float* slab, int ntiles, int C, float* sums, void* stream);
+
+/* y = relu?( raw*scale + shift  [+ res_raw*res_scale + res_shift | + res] ) -> bf16 [M][C]
+ * (adaptseg:86-87,90-91,94,96-100).  raw, res: bf16 [M][C]; res_scale == NULL means `res` is an
+ * already-normalised activation; res == NULL means no residual. */
+int diga_bn_apply(const void* raw, const float* scale, const float* shift, const void* res,
+                  const float* res_scale, const float* res_shift, void* out, int64_t M, int C,
+                  int relu, void* stream);
+
+/* The stand-alone module form (SIFABatchNorm2dTrainable.forward on an fp32 NCHW tensor, ttda:299-345):
+ * per-channel shifted sums with 64-lane wavefront-shuffle reductions -> a 1-tile slab for
+ * diga_bn_finalize (group A = samples [0, split_b), group B = the rest), then y = x*scale + shift. */
+int diga_bn_stats_nchw_f32(const float* x, int B, int C, int HW, int split_b, const float* stat_shift,
+                           float* slab, void* stream);
+int diga_bn_apply_nchw_f32(const float* x, const float* scale, const float* shift, float* out, int B,
+                           int C, int HW, void* stream);
+
+/* bn1 + ReLU + MaxPool2d(3, stride 2, pad 1, ceil_mode=True) fused (adaptseg:179-181,139):
+ * raw bf16 NHWC [B,H,W,C] -> bf16 NHWC [B,Ho,Wo,C], Ho = ceil((H-1)/2)+1 (PyTorch ceil rule). */
+int diga_bn_relu_maxpool(const void* raw, const float* scale, const float* shift, void* out, int B,
+                         int H, int W, int C, int Ho, int Wo, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SAM (ttda:1662-1805) and fusion (ttda:1644)
+ * ------------------------------------------------------------------------------------------ */
+/* Sum split-K head partials + bias -> logits fp32 NCHW [B,C,h,w]; softmax/argmax/threshold ->
+ * pseudo-labels int32 [B*h*w] (255 = not confident; strict '<', ttda:1675) (ttda:1662-1676).
+ * partials: fp32 [splitk][M][cpad] (M = B*h*w) or NULL when logits_in is given (NCHW fp32). */
+int diga_head_finish_pseudo_label(const float* partials, int splitk, int cpad, const float* bias_sum,
+                                  const float* logits_in, float* logits_out, int32_t* labels,
+                                  int B, int C, int hw, float threshold, void* stream);
+
+/* F.interpolate(y.float(), size=(h,w), mode='nearest').long() (ttda:1695): src = floor(dst*in/out)
+ * computed as the reference does (fp32 scale).  y: int64 (y_is_i64) or int32 [B,H,W] -> int32 [B,h,w]. */
+int diga_nearest_down_labels(const void* y, int y_is_i64, int32_t* out, int B, int H, int W, int h,
+                             int w, void* stream);
+
+/* cal_proto (ttda:1788-1805) for up to two label sets in one call.  Stable (pixel-order) per-class
+ * index lists, then chunked register-accumulated row sums -- deterministic.
+ * feat: bf16 [P][CH]; labels: int32 [nsets][P]; work: scratch, diga_proto_pool_work_bytes() bytes;
+ * sums: fp32 [nsets][C][CH]; counts: int32 [nsets][C]. */
+int64_t diga_proto_pool_work_bytes(int nsets, int64_t P, int C, int CH);
+int diga_proto_pool(const void* feat, const int32_t* labels, int nsets, int64_t P, int C, int CH,
+                    void* work, float* sums, int32_t* counts, void* stream);
+
+/* Instance prototypes + running-prototype seed / EMA (ttda:1700-1705, 1736-1765).
+ * sums/counts: as produced by diga_proto_pool with set 0 = pseudo-labels, set 1 = ground truth
+ * (all-reduced over ranks in the sharded path).  state_flag: int32[1] device word, 0 before the
+ * first frame; set to 1 by this call.  one_minus_rho / rho are passed separately because the
+ * reference forms them in double precision (ttda:1764). */
+int diga_proto_update(const float* sums, const int32_t* counts, int C, int CH, float* inst_proto,
+                      float* inst_flag, float* run_proto, float* run_flag, int32_t* state_flag,
+                      float one_minus_rho, float rho, void* stream);
+
+/* cal_pred_of_proto x2 + proto blend + softmax fusion (ttda:1707-1709,1712-1734,1644):
+ *   out = fl*(pl*P_run + pl1*P_inst) + fl1*softmax(logits),  P_x[c] = exp(-||proto_x[c]-f||)*flag/sum
+ * 0/0 -> NaN is reproduced.  feat bf16 [P][CH]; logits fp32 NCHW [B,C,hw]; out fp32 NCHW [B,C,hw]. */
+int diga_proto_classify_fuse(const void* feat, const float* logits, const float* inst_proto,
+                             const float* inst_flag, const float* run_proto, const float* run_flag,
+                             float* out, int B, int C, int hw, int CH, float tau, float pl, float pl1,
+                             float fl, float fl1, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tail (ttda:1610, 158-173): bilinear upsample (align_corners=False) + argmax + confusion matrix.
+ * probs fp32 NCHW [B,C,h,w]; target int64/int32 [B,H,W]; pred uint8 [B,H,W] (may be NULL);
+ * hist int64 [C*C] += bincount(C*target+pred) * B for 0 <= target < C; probs_up (may be NULL)
+ * fp32 NCHW [B,C,H,W]. */
+int diga_upsample_argmax_hist(const float* probs, const void* target, int target_is_i64, uint8_t* pred,
+                              int64_t* hist, float* probs_up, int B, int C, int h, int w, int H, int W,
+                              void* stream);
+
+/* Layout helpers for the Python-visible API (net(x, feat=True) returns NCHW fp32, adaptseg:188). */
+int diga_nhwc_bf16_to_nchw_f32(const void* in, float* out, int B, int HW, int C, void* stream);
+int diga_nchw_f32_to_nhwc_bf16(const float* in, void* out, int B, int HW, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIGA_HIP_H */

@@ -98,7 +98,7 @@ def gen_fn_sam(m):
     out["pl_logits"], out["pl_labels"] = np_(logits), np_(pl)
     # -- cal_proto: empty classes + 255
     for B in (1, 2):
-        feat = torch.randn(B, CH, h, w, generator=g).relu()
+        feat = torch.randn(B, CH, h, w, generator=g).relu().bfloat16().float()   # bf16-representable: the kernels store features as bf16
         lab = torch.randint(0, 12, (B, h, w), generator=g)         # classes 12..18 empty
         lab[torch.rand(B, h, w, generator=g) < 0.2] = 255
         lab[lab == 5] = 4                                           # class 5 empty too
@@ -106,7 +106,7 @@ def gen_fn_sam(m):
             proto, flag = m.cal_proto(feat, lab)
         out[f"cp{B}_feat"], out[f"cp{B}_lab"], out[f"cp{B}_proto"], out[f"cp{B}_flag"] = map(np_, (feat, lab, proto, flag))
     # -- _update_classifier_proto: first-seen / EMA / rho = 0
-    feat = torch.randn(1, CH, h, w, generator=g).relu()
+    feat = torch.randn(1, CH, h, w, generator=g).relu().bfloat16().float()
     y = torch.randint(0, 10, (1, h, w), generator=g)
     run = torch.randn(C, CH, generator=g)
     rflag = torch.zeros(C)
@@ -119,7 +119,7 @@ def gen_fn_sam(m):
                      up_run_rho0=r0, up_flag_rho0=f0).items():
         out[k] = np_(v)
     # -- cal_pred_of_proto: normal, all-flags-zero -> NaN, far prototypes -> underflow NaN / partial underflow
-    feat = torch.randn(2, CH, h, w, generator=g).relu() * 0.5
+    feat = (torch.randn(2, CH, h, w, generator=g).relu() * 0.5).bfloat16().float()
     proto = torch.randn(C, CH, generator=g).relu() * 0.5
     flag = (torch.rand(C, generator=g) < 0.7).float()
     far = proto.clone()
@@ -137,7 +137,7 @@ def gen_fn_sam(m):
         if hasattr(m, "classifier_running_proto"):
             del m.classifier_running_proto
         for t in range(3):
-            feat = torch.randn(B, CH, h, w, generator=g).relu() * 0.5
+            feat = (torch.randn(B, CH, h, w, generator=g).relu() * 0.5).bfloat16().float()
             lg = torch.randn(B, C, h, w, generator=g) * 5
             y = torch.randint(0, 14, (B, 37, 45), generator=g)
             y[torch.rand(B, 37, 45, generator=g) < 0.1] = 255

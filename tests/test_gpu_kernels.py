@@ -1,0 +1,218 @@
+"""-m gpu: kernel-level parity of libdiga_hip.so (through the C-ABI) against the CPU oracle.
+
+Stage-isolated contract (SURVEY.md section 7 hard part 1): every kernel is fed inputs that are exactly
+representable in its storage type, the oracle is fed the same values in fp32, so the only differences
+are fp32 summation order and the final bf16 rounding of stored activations:
+  * bf16 activations: |gpu - bf16(oracle)| <= 1 bf16 ulp  (2^-8 relative to the tensor scale here)
+  * fp32 outputs (statistics -> scale/shift, logits): <= 1e-4 relative (north-star bar: 1e-3)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DEV, P, bf16_round, call, conv_desc, from_nhwc_bf16, rel_err, stream, to_nhwc_bf16
+from oracle import diga_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF16_TOL = 2.0 ** -7   # one bf16 spacing at the tensor scale (RNE error is half of it, a flipped rounding a full one)
+
+
+def _bn_params(Cc, g):
+    rm = torch.randn(Cc, generator=g) * 0.3
+    rv = torch.rand(Cc, generator=g) + 0.5
+    w = torch.rand(Cc, generator=g) + 0.5
+    b = torch.randn(Cc, generator=g) * 0.1
+    return rm, rv, w, b
+
+
+def _oracle_scale_shift(ref_out, rm, rv, w, b, lam=0.8, eps=1e-5):
+    mean_cur, var_cur = O.dam_current_stats(ref_out)
+    lam_t = torch.tensor(lam, dtype=torch.float32)
+    mean = lam_t * rm + (1 - lam_t) * mean_cur
+    var = lam_t * rv + (1 - lam_t) * var_cur
+    sc = w / torch.sqrt(var + eps)
+    return sc, b - mean * sc
+
+
+CONV_CASES = [
+    # B, H,  W,  Cin, Cout, stride, k3,   dil, tile
+    (1, 9, 17, 64, 64, 1, False, 1, 3),
+    (1, 17, 33, 256, 128, 2, False, 1, 2),
+    (2, 9, 17, 128, 128, 1, True, 2, 1),
+    (1, 13, 21, 64, 256, 1, True, 4, 4),
+    (3, 9, 17, 64, 64, 1, True, 1, 0),
+    (1, 33, 65, 64, 256, 1, False, 1, 0),
+    (2, 17, 33, 128, 64, 1, True, 1, 3),
+    (1, 23, 31, 512, 512, 1, True, 4, 0),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,k3,dil,tile", CONV_CASES)
+def test_conv_igemm(B, H, W, Cin, Cout, stride, k3, dil, tile):
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin + Cout + dil)
+    x = bf16_round(torch.randn(B, Cin, H, W, generator=g).relu() + 0.1 * torch.randn(B, Cin, H, W, generator=g))
+    ks = 3 if k3 else 1
+    wt = bf16_round(torch.randn(Cout, Cin, ks, ks, generator=g) * (2.0 / (Cin * ks * ks)) ** 0.5)
+    rm, rv, bw, bb = _bn_params(Cout, g)
+    ref = F.conv2d(x, wt, stride=stride, padding=dil if k3 else 0, dilation=dil if k3 else 1)
+    Ho, Wo = ref.shape[2:]
+    d = conv_desc(B, H, W, Cin, Cout, stride, k3, dil, split_row=(Ho * Wo if B > 1 else None), tile=tile)
+    assert (d.Ho, d.Wo) == (Ho, Wo)
+    xin = to_nhwc_bf16(x)
+    wp = wt.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(torch.bfloat16).to(DEV)
+    out = torch.zeros(B * Ho * Wo * Cout, dtype=torch.bfloat16, device=DEV)
+    nt = call("diga_conv_num_mtiles", C.byref(d))
+    slab = torch.full((nt * 4 * Cout,), float("nan"), dtype=torch.float32, device=DEV)
+    dv = [t.to(DEV) for t in (rm, rv, bw, bb)]
+    call("diga_conv_igemm_bf16", C.byref(d), P(xin), P(wp), P(out), P(slab), P(dv[0]), stream())
+    sc = torch.empty(Cout, dtype=torch.float32, device=DEV)
+    sh = torch.empty(Cout, dtype=torch.float32, device=DEV)
+    n_a = float(Ho * Wo)
+    n_b = float((B - 1) * Ho * Wo)
+    call("diga_bn_finalize", P(slab), nt, Cout, n_a, n_b, P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), 0.8, 1e-5, P(sc), P(sh), stream())
+    torch.cuda.synchronize()
+    got = from_nhwc_bf16(out, (B, Ho, Wo, Cout))
+    e = rel_err(got, bf16_round(ref))
+    assert e <= BF16_TOL, f"raw conv output rel err {e}"
+    rsc, rsh = _oracle_scale_shift(ref, rm, rv, bw, bb)
+    assert rel_err(sc.cpu(), rsc) < 1e-4 and rel_err(sh.cpu(), rsh) < 1e-4, (rel_err(sc.cpu(), rsc), rel_err(sh.cpu(), rsh))
+
+
+def test_conv_rejects_bad_shapes():
+    from diga_amd._lib import DigaError
+    d = conv_desc(1, 9, 17, 48, 64)       # Cin not a multiple of 64
+    with pytest.raises(DigaError, match="Cin"):
+        call("diga_conv_num_mtiles", C.byref(d))
+
+
+@pytest.mark.parametrize("B,h,w,splitk", [(1, 9, 17, 4), (2, 13, 21, 3), (1, 33, 65, 1)])
+def test_head_conv_and_pseudo_labels(B, h, w, splitk):
+    """Fused 2-branch head (dil 6 + dil 12, adaptseg:119-121) as one 18-tap split-K igemm + finish."""
+    g = torch.Generator().manual_seed(7 + h)
+    CH, NC = 2048, 19
+    feat = bf16_round(torch.randn(B, CH, h, w, generator=g).relu() * 0.3)
+    w0 = bf16_round(torch.randn(NC, CH, 3, 3, generator=g) * 0.05)
+    w1 = bf16_round(torch.randn(NC, CH, 3, 3, generator=g) * 0.05)
+    b0, b1 = torch.randn(NC, generator=g) * 0.5, torch.randn(NC, generator=g) * 0.5
+    p = {"layer6.conv2d_list.0.weight": w0, "layer6.conv2d_list.0.bias": b0, "layer6.conv2d_list.1.weight": w1,
+         "layer6.conv2d_list.1.bias": b1}
+    ref = O.head_logits(p, feat)
+    d = conv_desc(B, h, w, CH, NC, cout_pad=32, tile=5)
+    d.ntaps = 18
+    for br, dil in enumerate((6, 12)):
+        for t in range(9):
+            d.dy[br * 9 + t], d.dx[br * 9 + t] = (t // 3 - 1) * dil, (t % 3 - 1) * dil
+    d.splitk, d.out_f32 = splitk, 1
+    hw = torch.cat([w0.permute(0, 2, 3, 1).reshape(NC, -1), w1.permute(0, 2, 3, 1).reshape(NC, -1)], 1)
+    hw = torch.cat([hw, torch.zeros(32 - NC, hw.shape[1])], 0).to(torch.bfloat16).to(DEV)
+    Pn = B * h * w
+    part = torch.full((splitk * Pn * 32,), float("nan"), dtype=torch.float32, device=DEV)
+    call("diga_conv_igemm_bf16", C.byref(d), P(to_nhwc_bf16(feat)), P(hw), P(part), None, None, stream())
+    logits = torch.empty(B, NC, h, w, dtype=torch.float32, device=DEV)
+    labels = torch.empty(Pn, dtype=torch.int32, device=DEV)
+    bias = (b0 + b1).to(DEV)
+    call("diga_head_finish_pseudo_label", P(part), splitk, 32, P(bias), None, P(logits), P(labels), B, NC, h * w, float(np.float32(0.9)),
+         stream())
+    torch.cuda.synchronize()
+    assert rel_err(logits.cpu(), ref) < 1e-4
+    # pseudo labels from the GPU's own logits must match the oracle applied to those logits, except within 1e-6 of the bar
+    lg = logits.cpu()
+    want = O.pseudo_labels(lg, 0.9).reshape(-1).numpy()
+    pm = lg.softmax(1).max(1)[0].reshape(-1).numpy()
+    safe = np.abs(pm - 0.9) > 1e-6
+    got = labels.cpu().numpy()
+    assert np.array_equal(got[safe], want[safe])
+    assert (~safe).sum() <= 2
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 65, 129), (2, 47, 35), (1, 129, 257)])
+def test_stem_bn_maxpool(B, H, W):
+    g = torch.Generator().manual_seed(H)
+    x = (torch.randn(B, 3, H, W, generator=g) * 50).clamp(-123, 151)
+    wt = torch.randn(64, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5
+    rm, rv, bw, bb = _bn_params(64, g)
+    ref = F.conv2d(x, wt, stride=2, padding=3)
+    Ho, Wo = ref.shape[2:]
+    nt = call("diga_stem_conv7x7s2", None, None, None, None, None, B, H, W, 0, None)
+    out = torch.zeros(B * Ho * Wo * 64, dtype=torch.bfloat16, device=DEV)
+    slab = torch.full((nt * 4 * 64,), float("nan"), dtype=torch.float32, device=DEV)
+    dv = [t.to(DEV) for t in (rm, rv, bw, bb)]
+    split = Ho * Wo if B > 1 else B * Ho * Wo
+    call("diga_stem_conv7x7s2", P(x.to(DEV)), P(wt.to(DEV)), P(out), P(slab), P(dv[0]), B, H, W, split, stream())
+    sc = torch.empty(64, dtype=torch.float32, device=DEV)
+    sh = torch.empty(64, dtype=torch.float32, device=DEV)
+    call("diga_bn_finalize", P(slab), nt, 64, float(Ho * Wo), float((B - 1) * Ho * Wo), P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), 0.8,
+         1e-5, P(sc), P(sh), stream())
+    torch.cuda.synchronize()
+    got = from_nhwc_bf16(out, (B, Ho, Wo, 64))
+    assert rel_err(got, bf16_round(ref)) <= BF16_TOL
+    rsc, rsh = _oracle_scale_shift(ref, rm, rv, bw, bb)
+    assert rel_err(sc.cpu(), rsc) < 1e-4 and rel_err(sh.cpu(), rsh) < 1e-4
+    # bn1 + relu + ceil-mode maxpool on the GPU's own raw output / affine
+    from diga_amd.engine import pool_out
+    Hp, Wp = pool_out(Ho), pool_out(Wo)
+    pooled = torch.zeros(B * Hp * Wp * 64, dtype=torch.bfloat16, device=DEV)
+    call("diga_bn_relu_maxpool", P(out), P(sc), P(sh), P(pooled), B, Ho, Wo, 64, Hp, Wp, stream())
+    torch.cuda.synchronize()
+    y = torch.relu(got * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None])
+    refp = F.max_pool2d(y, 3, 2, 1, ceil_mode=True)
+    assert refp.shape[2:] == (Hp, Wp)
+    assert rel_err(from_nhwc_bf16(pooled, (B, Hp, Wp, 64)), bf16_round(refp)) <= BF16_TOL
+
+
+@pytest.mark.parametrize("Cc,mode", [(64, 0), (256, 1), (2048, 2), (512, 2), (1024, 1)])
+def test_bn_apply(Cc, mode):
+    g = torch.Generator().manual_seed(Cc + mode)
+    M = 1237
+    raw = bf16_round(torch.randn(M, Cc, generator=g) * 2)
+    res = bf16_round(torch.randn(M, Cc, generator=g))
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    rsc, rsh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    ref = raw * sc + sh
+    if mode == 1:
+        ref = ref + res
+    if mode == 2:
+        ref = ref + (res * rsc + rsh)
+    ref = torch.relu(ref)
+    out = torch.zeros(M * Cc, dtype=torch.bfloat16, device=DEV)
+    d = lambda t: t.to(DEV)
+    call("diga_bn_apply", P(d(raw.to(torch.bfloat16))), P(d(sc)), P(d(sh)), P(d(res.to(torch.bfloat16))) if mode else None,
+         P(d(rsc)) if mode == 2 else None, P(d(rsh)) if mode == 2 else None, P(out), M, Cc, 1, stream())
+    torch.cuda.synchronize()
+    assert rel_err(out.float().cpu().reshape(M, Cc), bf16_round(ref)) <= BF16_TOL
+
+
+@pytest.mark.parametrize("B", [1, 2, 3])
+def test_standalone_dam_bn_matches_reference_fixture(gold_bn, B):
+    """SIFABatchNorm2dTrainable.forward (fp32 NCHW) against the reference's own output (fn_bn.npz)."""
+    gd = gold_bn
+    x = torch.from_numpy(gd[f"B{B}_x"]).to(DEV)
+    Bn, Cc, H, W = x.shape
+    prm = [torch.from_numpy(gd[f"B{B}_{k}"]).to(DEV) for k in ("running_mean", "running_var", "weight", "bias")]
+    slab = torch.empty(4 * Cc, dtype=torch.float32, device=DEV)
+    sc = torch.empty(Cc, dtype=torch.float32, device=DEV)
+    sh = torch.empty(Cc, dtype=torch.float32, device=DEV)
+    y = torch.empty_like(x)
+    split_b = 1 if B > 1 else B
+    call("diga_bn_stats_nchw_f32", P(x), Bn, Cc, H * W, split_b, P(prm[0]), P(slab), stream())
+    call("diga_bn_finalize", P(slab), 1, Cc, float(split_b * H * W), float((B - split_b) * H * W), P(prm[0]), P(prm[1]), P(prm[2]),
+         P(prm[3]), 0.8, 1e-5, P(sc), P(sh), stream())
+    call("diga_bn_apply_nchw_f32", P(x), P(sc), P(sh), P(y), Bn, Cc, H * W, stream())
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), gd[f"B{B}_y"]) < 2e-6
+
+
+def test_layout_roundtrip():
+    g = torch.Generator().manual_seed(5)
+    x = bf16_round(torch.randn(2, 70, 9, 13, generator=g))
+    nhwc = torch.zeros(2 * 9 * 13 * 70, dtype=torch.bfloat16, device=DEV)
+    call("diga_nchw_f32_to_nhwc_bf16", P(x.to(DEV)), P(nhwc), 2, 9 * 13, 70, stream())
+    back = torch.zeros(2, 70, 9, 13, dtype=torch.float32, device=DEV)
+    call("diga_nhwc_bf16_to_nchw_f32", P(nhwc), P(back), 2, 9 * 13, 70, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(back.cpu(), x)
+    assert torch.equal(from_nhwc_bf16(nhwc, (2, 9, 13, 70)), x)
