@@ -1,0 +1,185 @@
+"""Benchmark: adapted frames/s of the DIGA backward-free TTA path (DeepLabV2-R101 + DAM + SAM + fusion +
+full-resolution arg-max/confusion tail) on synthetic 1024x512 frames.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: N=1 -> BASELINE.json configs[1] (batch-1 online stream on
+one MI355X, one frame per step); N>1 -> configs[2] (global batch N = one frame per GPU, BN sum/sumsq and
+prototype sums/counts all-reduced over RCCL; weak scaling).  Inputs and labels are resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(bn_lambda=0.8, proto_lambda=0.8, fusion_lambda=0.8, confidence_threshold=0.9, proto_rho=0.1)
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_HBM_GBS = 8000.0          # HBM3E spec peak, same guide
+
+
+def conv_profile(eng, frames, cfg, reps=3):
+    """Per-launch HIP-event timing (on the launch stream) of every igemm conv of a frame, eager mode."""
+    out = None
+    for r in range(reps + 1):
+        eng.conv_events = []
+        x, y = frames[r % len(frames)]
+        eng.forward_and_adapt(x, y, cfg)
+        torch.cuda.synchronize()
+        ev = eng.conv_events
+        eng.conv_events = None
+        if r == 0:
+            continue           # warm-up
+        ms = np.array([s.elapsed_time(e) for (_, _, s, e) in ev])
+        out = ms if out is None else out + ms
+        meta = [(n, f) for (n, f, _, _) in ev]
+    return meta, out / reps
+
+
+def cpu_baseline(nframes_timed=2, H=512, W=1024):
+    """The CPU oracle (a restatement of the reference's PyTorch CPU path; oracle/diga_oracle.py) on the host
+    cores of this box: 1 warm-up + nframes_timed frames of forward_and_adapt + upsample + metric."""
+    from diga_amd import synth
+    from oracle import diga_oracle as O
+    p = O.to_torch(synth.synth_params(0))
+    st = O.SamState()
+    hist = torch.zeros(19, 19)
+    t0 = None
+    with torch.no_grad():
+        for t in range(nframes_timed + 1):
+            x, y = synth.synth_frame(t, 1, H, W)
+            if t == 1:
+                t0 = time.perf_counter()
+            probs = O.forward_and_adapt(p, st, torch.from_numpy(x), torch.from_numpy(y), CFG)
+            hist = O.metric_update(hist, O.upsample_probs(probs, y.shape[-2:]), torch.from_numpy(y))
+    dt = time.perf_counter() - t0
+    return dict(value=round(nframes_timed / dt, 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{nframes_timed} frames 1024x512 batch 1 after 1 warm-up (oracle forward_and_adapt + bilinear upsample + "
+                       f"confusion matrix), torch {torch.__version__} CPU")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump", default=None, help="write the per-conv timing table to this JSON file")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        group = dist.group.WORLD
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    H, W = args.height, args.width
+    weights = NetWeights(synth.synth_params(0), dev)
+    eng = Engine(weights, 1, H, W, bn_lambda=CFG["bn_lambda"], group=group)
+    nf = 4
+    frames = []
+    for i in range(nf):
+        x, y = synth.synth_frame(1000 + i * world + rank, 1, H, W)
+        frames.append((torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)))
+
+    def step_eager(i):
+        x, y = frames[i % nf]
+        eng.forward_and_adapt(x, y, CFG)
+        eng.tail(y)
+
+    use_graph = (world == 1) and not args.no_graph
+    step_eager(0)
+    step_eager(1)
+    torch.cuda.synchronize()
+    if use_graph:
+        graphs = []
+        for i in range(nf):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step_eager(i)
+            graphs.append(g)
+
+        def step(i):
+            graphs[i % nf].replay()
+    else:
+        step = step_eager
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    fps = world * args.steps / dt
+
+    res = {
+        "metric": "adapted frames/sec DeepLabV2-R101 DIGA (DAM+SAM) 1024x512", "value": round(fps, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": ("BASELINE configs[1]: DIGA TTA stream (DAM+SAM, 19 classes), batch 1 per step, online prototype/BN-stat "
+                                "updates" if world == 1 else
+                                f"BASELINE configs[2]: global batch {world} = 1 frame per GPU, BN sum/sumsq + prototype sums all-reduced (RCCL)"),
+                   "resolution": f"{W}x{H}", "feature_grid": f"{eng.wd}x{eng.h}", "weights": "seeded synthetic init (diga_amd/synth.py)",
+                   "launch": "hipGraph replay" if use_graph else "eager", "includes": "net + SAM + fusion + upsample/argmax/confusion tail",
+                   "conv_gflop_per_frame": round(eng.conv_flops / 1e9, 3)},
+    }
+    if rank == 0 and world == 1 and not args.no_roofline:
+        meta, ms = conv_profile(eng, frames, CFG)
+        total_ms = float(ms.sum())
+        igemm_flops = float(sum(f for _, f in meta))
+        ach = igemm_flops / (total_ms * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (all igemm launches of one frame)",
+                           "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                           "traffic": None, "launches_per_frame": len(meta), "avg_launch_us": round(total_ms * 1e3 / len(meta), 2),
+                           "kernel_ms_per_frame": round(total_ms, 4), "algorithmic_gflop_per_frame": round(igemm_flops / 1e9, 3)}
+        if args.dump:
+            with open(args.dump, "w") as f:
+                json.dump([dict(name=n, gflop=fl / 1e9, us=float(m) * 1e3, tflops=fl / (float(m) * 1e-3) / 1e12)
+                           for (n, fl), m in zip(meta, ms)], f, indent=0)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,6 +185,7 @@ class Engine:
         self.hist = torch.zeros(self.C * self.C, dtype=torch.int64, device=dev)
         self.feat = None          # bf16 NHWC view of the layer4 output, set by forward_feat
         self.conv_flops = 0       # 2*MAC of the executed convs (filled by the first forward_feat)
+        self.conv_events = None   # optional list: (name, flops, start_event, end_event) per igemm launch (bench.py)
         self.taps = None          # optional dict: name -> (tensor, shape) of intermediate activations (tests)
 
     # ------------------------------------------------------------------ helpers
@@ -224,10 +225,26 @@ class Engine:
         d.split_row = self._groups(Ho * Wo)[0]
         d.splitk, d.out_f32, d.tile = 1, 0, 0
         nt = call("diga_conv_num_mtiles", C.byref(d))
+        flops = 2 * self.B * Ho * Wo * Cout * Cin * d.ntaps
+        ev = self._ev_start()
         call("diga_conv_igemm_bf16", C.byref(d), _p(x), _p(self.w.conv[name]), _p(out), _p(self.slab), _p(bn.running_mean),
              _stream())
-        self.conv_flops += 2 * self.B * Ho * Wo * Cout * Cin * d.ntaps
+        self._ev_end(ev, name, flops)
+        self.conv_flops += flops
         return nt
+
+    def _ev_start(self):
+        if self.conv_events is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _ev_end(self, start, name, flops):
+        if start is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.conv_events.append((name, flops, start, e))
 
     def _tap(self, name, t, shape):
         if self.taps is not None:
@@ -309,7 +326,9 @@ class Engine:
         d.cout_pad = self.w.head_cpad
         d.split_row = self.P
         d.splitk, d.out_f32, d.tile = self.head_splitk, 1, 5
+        ev = self._ev_start()
         call("diga_conv_igemm_bf16", C.byref(d), _p(feat), _p(hw), _p(self.head_part), None, None, _stream())
+        self._ev_end(ev, "head", 2 * self.P * self.C * cin * 18)
         self.conv_flops += 2 * self.P * self.C * cin * 18
         # split-K partials + bias -> logits (NCHW fp32) and the confidence-thresholded pseudo labels (ttda:1662-1676)
         call("diga_head_finish_pseudo_label", _p(self.head_part), self.head_splitk, self.w.head_cpad, _p(hbias), None,

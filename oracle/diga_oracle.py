@@ -121,6 +121,68 @@ def net_forward_feat(p: dict, x: torch.Tensor, lam: float = 0.8, taps: dict | No
     return feat, logits
 
 
+def bf16_round(t: torch.Tensor) -> torch.Tensor:
+    """fp32 -> nearest-even bf16 -> fp32 (the storage rounding of the GPU pipeline)."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def dam_affine(x_raw, running_mean, running_var, weight, bias, lam, eps=1e-5):
+    """Per-channel (scale, shift) with y = x*scale + shift == dam_bn(x) (the form the GPU applies)."""
+    mean_cur, var_cur = dam_current_stats(x_raw)
+    lam = torch.as_tensor(lam, dtype=torch.float32)
+    mean = lam * running_mean + (1 - lam) * mean_cur
+    var = lam * running_var + (1 - lam) * var_cur
+    sc = weight / torch.sqrt(var + eps)
+    return sc, bias - mean * sc
+
+
+def net_forward_feat_bf16(p: dict, x: torch.Tensor, lam: float = 0.8, taps: dict | None = None):
+    """The same network with the GPU pipeline's *storage* precision emulated: conv weights (except the
+    fp32 stem) and every stored activation are rounded to bf16, all arithmetic stays fp32, and the DAM
+    statistics are taken from the un-rounded fp32 conv outputs (as the conv epilogue does).  This is
+    the oracle for end-to-end parity of the bf16 path: it differs from ``net_forward_feat`` only by
+    rounding, and the GPU differs from it only by fp32 summation order."""
+    r = bf16_round
+
+    def aff(prefix, raw):
+        return dam_affine(raw, p[prefix + ".running_mean"], p[prefix + ".running_var"], p[prefix + ".weight"],
+                          p[prefix + ".bias"], lam)
+
+    def app(raw_q, sc, sh):
+        return raw_q * sc[None, :, None, None] + sh[None, :, None, None]
+
+    raw = F.conv2d(x, p["conv1.weight"], stride=2, padding=3)
+    sc, sh = aff("bn1", raw)
+    if taps is not None:
+        taps["conv1"] = r(raw)
+    cur = r(F.max_pool2d(torch.relu(app(r(raw), sc, sh)), 3, 2, 1, ceil_mode=True))
+    if taps is not None:
+        taps["maxpool"] = cur
+    for li, (nb, st, dil) in enumerate(zip(LAYERS, STRIDES, DILATIONS), start=1):
+        for b in range(nb):
+            pre = f"layer{li}.{b}"
+            s = st if b == 0 else 1
+            raw1 = F.conv2d(cur, r(p[pre + ".conv1.weight"]), stride=s)
+            sc, sh = aff(pre + ".bn1", raw1)
+            a1 = r(torch.relu(app(r(raw1), sc, sh)))
+            raw2 = F.conv2d(a1, r(p[pre + ".conv2.weight"]), padding=dil, dilation=dil)
+            sc, sh = aff(pre + ".bn2", raw2)
+            a2 = r(torch.relu(app(r(raw2), sc, sh)))
+            raw3 = F.conv2d(a2, r(p[pre + ".conv3.weight"]))
+            sc3, sh3 = aff(pre + ".bn3", raw3)
+            if b == 0:
+                rawd = F.conv2d(cur, r(p[pre + ".downsample.0.weight"]), stride=s)
+                scd, shd = aff(pre + ".downsample.1", rawd)
+                res = app(r(rawd), scd, shd)
+            else:
+                res = cur
+            cur = r(torch.relu(app(r(raw3), sc3, sh3) + res))
+            if taps is not None:
+                taps[pre] = cur
+    hp = {k: (r(v) if k.endswith("weight") else v) for k, v in p.items() if k.startswith("layer6.")}
+    return cur, head_logits(hp, cur)
+
+
 def head_logits(p, feat):
     return (F.conv2d(feat, p["layer6.conv2d_list.0.weight"], p["layer6.conv2d_list.0.bias"], padding=6, dilation=6)
             + F.conv2d(feat, p["layer6.conv2d_list.1.weight"], p["layer6.conv2d_list.1.bias"], padding=12, dilation=12))
@@ -218,9 +280,9 @@ def fuse(multi_pred, logits, fusion_lambda):
     return multi_pred * fusion_lambda + logits.softmax(1) * (1 - fusion_lambda)
 
 
-def forward_and_adapt(p, state: SamState, x, y, cfg, info: dict | None = None):
-    """ttda:1623-1645 (without the .cpu())."""
-    feat, logits = net_forward_feat(p, x, cfg["bn_lambda"])
+def forward_and_adapt(p, state: SamState, x, y, cfg, info: dict | None = None, bf16: bool = False):
+    """ttda:1623-1645 (without the .cpu()).  bf16=True uses the storage-precision emulation of the GPU path."""
+    feat, logits = (net_forward_feat_bf16 if bf16 else net_forward_feat)(p, x, cfg["bn_lambda"])
     if info is not None:
         info.update(feature=feat, logits=logits)
     return fuse(multi_proto_label(state, feat, logits, y, cfg, info), logits, cfg["fusion_lambda"])

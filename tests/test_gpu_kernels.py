@@ -111,7 +111,8 @@ def test_head_conv_and_pseudo_labels(B, h, w, splitk):
     hw = torch.cat([hw, torch.zeros(32 - NC, hw.shape[1])], 0).to(torch.bfloat16).to(DEV)
     Pn = B * h * w
     part = torch.full((splitk * Pn * 32,), float("nan"), dtype=torch.float32, device=DEV)
-    call("diga_conv_igemm_bf16", C.byref(d), P(to_nhwc_bf16(feat)), P(hw), P(part), None, None, stream())
+    fd = to_nhwc_bf16(feat)
+    call("diga_conv_igemm_bf16", C.byref(d), P(fd), P(hw), P(part), None, None, stream())
     logits = torch.empty(B, NC, h, w, dtype=torch.float32, device=DEV)
     labels = torch.empty(Pn, dtype=torch.int32, device=DEV)
     bias = (b0 + b1).to(DEV)
@@ -142,7 +143,8 @@ def test_stem_bn_maxpool(B, H, W):
     slab = torch.full((nt * 4 * 64,), float("nan"), dtype=torch.float32, device=DEV)
     dv = [t.to(DEV) for t in (rm, rv, bw, bb)]
     split = Ho * Wo if B > 1 else B * Ho * Wo
-    call("diga_stem_conv7x7s2", P(x.to(DEV)), P(wt.to(DEV)), P(out), P(slab), P(dv[0]), B, H, W, split, stream())
+    xd, wd = x.to(DEV), wt.to(DEV)      # keep device copies alive until the kernels have run
+    call("diga_stem_conv7x7s2", P(xd), P(wd), P(out), P(slab), P(dv[0]), B, H, W, split, stream())
     sc = torch.empty(64, dtype=torch.float32, device=DEV)
     sh = torch.empty(64, dtype=torch.float32, device=DEV)
     call("diga_bn_finalize", P(slab), nt, 64, float(Ho * Wo), float((B - 1) * Ho * Wo), P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), 0.8,
@@ -179,9 +181,9 @@ def test_bn_apply(Cc, mode):
         ref = ref + (res * rsc + rsh)
     ref = torch.relu(ref)
     out = torch.zeros(M * Cc, dtype=torch.bfloat16, device=DEV)
-    d = lambda t: t.to(DEV)
-    call("diga_bn_apply", P(d(raw.to(torch.bfloat16))), P(d(sc)), P(d(sh)), P(d(res.to(torch.bfloat16))) if mode else None,
-         P(d(rsc)) if mode == 2 else None, P(d(rsh)) if mode == 2 else None, P(out), M, Cc, 1, stream())
+    rawd, resd, scd, shd, rscd, rshd = (t.to(DEV) for t in (raw.to(torch.bfloat16), res.to(torch.bfloat16), sc, sh, rsc, rsh))
+    call("diga_bn_apply", P(rawd), P(scd), P(shd), P(resd) if mode else None, P(rscd) if mode == 2 else None,
+         P(rshd) if mode == 2 else None, P(out), M, Cc, 1, stream())
     torch.cuda.synchronize()
     assert rel_err(out.float().cpu().reshape(M, Cc), bf16_round(ref)) <= BF16_TOL
 
@@ -210,7 +212,8 @@ def test_layout_roundtrip():
     g = torch.Generator().manual_seed(5)
     x = bf16_round(torch.randn(2, 70, 9, 13, generator=g))
     nhwc = torch.zeros(2 * 9 * 13 * 70, dtype=torch.bfloat16, device=DEV)
-    call("diga_nchw_f32_to_nhwc_bf16", P(x.to(DEV)), P(nhwc), 2, 9 * 13, 70, stream())
+    xd = x.to(DEV)
+    call("diga_nchw_f32_to_nhwc_bf16", P(xd), P(nhwc), 2, 9 * 13, 70, stream())
     back = torch.zeros(2, 70, 9, 13, dtype=torch.float32, device=DEV)
     call("diga_nhwc_bf16_to_nchw_f32", P(nhwc), P(back), 2, 9 * 13, 70, stream())
     torch.cuda.synchronize()

@@ -1,0 +1,195 @@
+"""-m gpu: whole-network parity of the HIP path (through the public DIGA / Engine API).
+
+Three levels (hard part 1):
+ 1. stage-isolated, real shapes: every conv / BN / residual stage of the 101-layer trunk is checked against
+    the oracle *fed the GPU's own input of that stage* -> <= 1 bf16 spacing for stored activations,
+    <= 1e-4 for fp32 logits.  This is the bit-level statement about the kernels.
+ 2. end-to-end vs the reference's fp32 outputs (tests/golden/net_small.npz, net_full.npz, produced by
+    the reference source itself): the bf16 storage of 130 intermediate tensors is a *precision choice of
+    the north star* (bf16 MFMA), not a kernel error, so this level is stated as agreement rates; the
+    same bounds hold for the oracle's own bf16-storage emulation (O.net_forward_feat_bf16), i.e. they are
+    the bf16 noise floor of this 101-layer net, not slack for the kernels:
+        logits  <= 6e-2 of the logit range, pseudo labels >= 95 % equal, final arg-max >= 93 % equal,
+        running-prototype flags identical, mIoU-19/16/13 within +-0.1 (the north-star bar).
+ 3. run-to-run determinism: bit-identical outputs (no atomics on floats anywhere in the path).
+"""
+import functools
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import bf16_round, from_nhwc_bf16, rel_err
+from diga_amd import synth
+from diga_amd import ttda_module as T
+from diga_amd.engine import DILATIONS, LAYERS, STRIDES, Engine, NetWeights
+from oracle import diga_oracle as O
+
+pytestmark = pytest.mark.gpu
+CFG = dict(bn_lambda=0.8, proto_lambda=0.8, fusion_lambda=0.8, confidence_threshold=0.9, proto_rho=0.1)
+NAMES = [f"c{i}" for i in range(19)]
+
+
+@pytest.fixture(scope="module")
+def weights(synth_params_np):
+    return NetWeights(synth_params_np, torch.device("cuda:0"))
+
+
+@pytest.fixture(scope="module")
+def diga(synth_params_np):
+    m = T.DIGA(net=functools.partial(T.DeepLabv2AdaptSeg, multi_level=True, restore_from=None),
+               dataset_info=dict(num_classes=19, image_size=(321, 321), test_list=[0], class_names=NAMES), cfg=CFG)
+    sd = {k: torch.from_numpy(v) for k, v in synth_params_np.items()}
+    missing, unexpected = m.net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("lambda_") for k in missing)
+    m._configure_bn_running_stats()
+    return m
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 65, 129), (2, 65, 129), (1, 129, 257)])
+def test_stage_isolated_whole_net(weights, synth_params_np, B, H, W):
+    pt = O.to_torch(synth_params_np)
+    eng = Engine(weights, B, H, W)
+    eng.taps = {}
+    x, _ = synth.synth_frame(0, B, H, W)
+    eng.forward_feat(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    taps = {k: from_nhwc_bf16(t, shp) for k, (t, shp) in eng.taps.items()}
+    ULP = 2.0 ** -7
+    bad = []
+
+    def chk(name, got, ref):
+        e = rel_err(got, bf16_round(ref))
+        if e > ULP:
+            bad.append((name, e))
+
+    def wq(k):
+        return bf16_round(pt[k])
+
+    def bn(prefix, raw):
+        return O._bn(pt, prefix, raw, 0.8)
+
+    raw = F.conv2d(torch.from_numpy(x), pt["conv1.weight"], stride=2, padding=3)
+    chk("conv1", taps["conv1"], raw)
+    chk("maxpool", taps["maxpool"], F.max_pool2d(torch.relu(bn("bn1", taps["conv1"])), 3, 2, 1, ceil_mode=True))
+    cur = taps["maxpool"]
+    for li, (nb, st, dil) in enumerate(zip(LAYERS, STRIDES, DILATIONS), start=1):
+        for b in range(nb):
+            pre = f"layer{li}.{b}"
+            s = st if b == 0 else 1
+            chk(pre + ".conv1", taps[pre + ".conv1"], F.conv2d(cur, wq(pre + ".conv1.weight"), stride=s))
+            chk(pre + ".act1", taps[pre + ".act1"], torch.relu(bn(pre + ".bn1", taps[pre + ".conv1"])))
+            chk(pre + ".conv2", taps[pre + ".conv2"], F.conv2d(taps[pre + ".act1"], wq(pre + ".conv2.weight"), padding=dil, dilation=dil))
+            chk(pre + ".act2", taps[pre + ".act2"], torch.relu(bn(pre + ".bn2", taps[pre + ".conv2"])))
+            chk(pre + ".conv3", taps[pre + ".conv3"], F.conv2d(taps[pre + ".act2"], wq(pre + ".conv3.weight")))
+            o3 = bn(pre + ".bn3", taps[pre + ".conv3"])
+            if b == 0:
+                chk(pre + ".downsample.0", taps[pre + ".downsample.0"], F.conv2d(cur, wq(pre + ".downsample.0.weight"), stride=s))
+                res = bn(pre + ".downsample.1", taps[pre + ".downsample.0"])
+            else:
+                res = cur
+            chk(pre, taps[pre], torch.relu(o3 + res))
+            cur = taps[pre]
+    assert not bad, bad[:5]
+    hp = {k: (bf16_round(v) if k.endswith("weight") else v) for k, v in pt.items() if k.startswith("layer6.")}
+    assert rel_err(eng.logits.cpu(), O.head_logits(hp, cur)) < 1e-4
+    assert torch.equal(eng.feat_nchw().cpu(), cur)
+    # pseudo labels: bit-exact w.r.t. the oracle applied to the GPU's own logits (outside 1e-6 of the bar)
+    lg = eng.logits.cpu()
+    pm = lg.softmax(1).max(1)[0].numpy()
+    safe = np.abs(pm - 0.9) > 1e-6
+    assert np.array_equal(eng.labels[:eng.P].cpu().numpy().reshape(pm.shape)[safe], O.pseudo_labels(lg, 0.9).numpy()[safe])
+
+
+def _run_gold_sequence(m, g, tag, B, H, W, nframes):
+    if hasattr(m, "classifier_running_proto"):
+        del m.classifier_running_proto
+    assert not hasattr(m, "classifier_running_proto")
+    metric = m.test_acc[0]
+    metric.reset()
+    stats = []
+    for t in range(nframes):
+        x, y = synth.synth_frame(t, B, H, W)
+        batch = (torch.from_numpy(x), torch.from_numpy(y), None, None)
+        m.test_step(batch, t)
+        eng = m._last_engine
+        torch.cuda.synchronize()
+        key = (lambda k: f"{tag}_{t}_{k}") if tag else (lambda k: f"{t}_{k}")
+        logits = eng.logits.cpu().numpy()
+        ref_logits = g[key("logits")]
+        pl = eng.labels[:eng.P].cpu().numpy().reshape(g[key("pseudo")].shape)
+        s = dict(logit_err=float(np.abs(logits - ref_logits).max() / (ref_logits.max() - ref_logits.min())),
+                 pseudo_agree=float((pl == g[key("pseudo")]).mean()),
+                 pred_agree=float((eng.pred.cpu().numpy() == g[key("pred")]).mean()),
+                 rflag_equal=bool(np.array_equal(m.classifier_running_proto_exists_flag.cpu().numpy(), g[key("rflag")])),
+                 probs_err=float(np.nanmax(np.abs(eng.probs.cpu().numpy() - g[key("probs")]))))
+        stats.append(s)
+        assert np.array_equal(np.isnan(eng.probs.cpu().numpy()), np.isnan(g[key("probs")]))
+    mious = [float(metric.compute()), float(metric.compute_iou("16")), float(metric.compute_iou("13"))]
+    return stats, mious
+
+
+@pytest.mark.parametrize("tag", ["s1", "s2", "s3", "m1"])
+def test_end_to_end_vs_reference_small(diga, gold_small, tag):
+    g = gold_small
+    B, H, W = (int(v) for v in g[f"{tag}_shape"])
+    stats, mious = _run_gold_sequence(diga, g, tag, B, H, W, 3)
+    print(tag, stats, mious, g[f"{tag}_miou"])
+    for s in stats:
+        assert s["logit_err"] <= 6e-2 and s["pseudo_agree"] >= 0.95 and s["pred_agree"] >= 0.93 and s["rflag_equal"], s
+    assert np.abs(np.array(mious) - g[f"{tag}_miou"]).max() <= 0.1          # north-star bar: mIoU within +-0.1
+
+
+def test_end_to_end_vs_reference_full_res(diga, gold_full):
+    """Two 1024x512 frames (prototype seeding branch, then the EMA branch) against the reference."""
+    stats, mious = _run_gold_sequence(diga, gold_full, "", 1, 512, 1024, 2)
+    print(stats, mious, gold_full["miou"])
+    for s in stats:
+        assert s["logit_err"] <= 6e-2 and s["pseudo_agree"] >= 0.95 and s["pred_agree"] >= 0.93 and s["rflag_equal"], s
+    assert np.abs(np.array(mious) - gold_full["miou"]).max() <= 0.1
+
+
+def test_run_to_run_determinism(weights):
+    outs = []
+    for _ in range(2):
+        eng = Engine(weights, 1, 129, 257)
+        x, y = synth.synth_frame(3, 1, 129, 257)
+        yd = torch.from_numpy(y).cuda()
+        for _t in range(2):
+            probs = eng.forward_and_adapt(torch.from_numpy(x).cuda(), yd, CFG)
+        eng.tail(yd)
+        torch.cuda.synchronize()
+        outs.append((probs.cpu().clone(), eng.pred.cpu().clone(), eng.hist.cpu().clone(), eng.run_proto.cpu().clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(torch.nan_to_num(a.float(), nan=-1.0), torch.nan_to_num(b.float(), nan=-1.0))
+
+
+def test_reference_api_surface(diga):
+    """Return types / shapes / state semantics of the mirrored API (ttda:1599-1645, 1702-1705)."""
+    m = diga
+    if hasattr(m, "classifier_running_proto"):
+        del m.classifier_running_proto
+    x, y = synth.synth_frame(5, 1, 65, 129)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    probs, info = m.forward_and_adapt((xt, yt))
+    assert probs.device.type == "cpu" and probs.shape == (1, 19, 9, 17) and info == {}
+    assert hasattr(m, "classifier_running_proto") and m.classifier_running_proto.shape == (19, 2048)
+    loss, up, ycpu, _ = m.step((xt, yt, None, None))
+    assert up.shape == (1, 19, 65, 129) and up.device.type == "cpu" and torch.equal(ycpu, yt)
+    feat, logits = m.net(xt.cuda(), feat=True)
+    assert feat.shape == (1, 2048, 9, 17) and logits.shape == (1, 19, 9, 17) and feat.dtype == torch.float32
+    x1, x2 = m.net(xt.cuda())
+    assert x1.shape == x2.shape == (1, 19, 9, 17) and torch.equal(x2, logits)
+    assert torch.equal(m(xt.cuda()), x2)
+    # helpers (NCHW fp32 in/out) agree with the oracle on the GPU's own features
+    pl = m.high_confident_proto_label(logits, 0.9)
+    assert pl.dtype == torch.int64 and pl.shape == (1, 9, 17)
+    proto, flag = m.cal_proto(feat, pl)
+    rp, rf = O.class_prototypes(feat.cpu(), pl.cpu())
+    assert torch.equal(flag.cpu(), rf) and rel_err(proto.cpu(), rp) < 1e-5
+    wgt = m.cal_pred_of_proto(feat, proto, flag)
+    ref_w = O.proto_probs(feat.cpu(), rp, rf)
+    assert np.nanmax(np.abs(wgt.cpu().numpy() - ref_w.numpy())) < 1e-4
+    with pytest.raises(T._lib.DigaError):
+        m.net(xt, feat=True)            # CPU tensor: no fallback

@@ -113,8 +113,9 @@ def _classify(feat_nchw, logits, ip, ifl, rp, rfl, pl=0.8, fl=0.8):
     B, CH, h, w = feat_nchw.shape
     out = torch.empty(B, NC, h, w, dtype=torch.float32, device=DEV)
     f32 = lambda v: float(np.float32(v))
-    call("diga_proto_classify_fuse", P(to_nhwc_bf16(feat_nchw)), P(logits.to(DEV)), P(ip.to(DEV)), P(ifl.to(DEV)), P(rp.to(DEV)),
-         P(rfl.to(DEV)), P(out), B, NC, h * w, CH, 1.0, f32(pl), f32(1 - pl), f32(fl), f32(1 - fl), stream())
+    keep = [to_nhwc_bf16(feat_nchw)] + [t.to(DEV) for t in (logits, ip, ifl, rp, rfl)]   # alive until synchronize()
+    call("diga_proto_classify_fuse", *(P(t) for t in keep), P(out), B, NC, h * w, CH, 1.0, f32(pl), f32(1 - pl), f32(fl), f32(1 - fl),
+         stream())
     torch.cuda.synchronize()
     return out.cpu()
 
@@ -202,7 +203,8 @@ def test_tail_fixture(gold_tail):
     if safe.all():
         assert np.array_equal(hist.cpu().numpy().reshape(C_, C_), g["tail_hist1"].astype(np.int64))
     # second update with the batch flipped accumulates (ttda:166)
-    call("diga_upsample_argmax_hist", P(probs.flip(0).contiguous()), P(tgt), 1, P(pred), P(hist), None, B, C_, h, w, H, W, stream())
+    flipped = probs.flip(0).contiguous()
+    call("diga_upsample_argmax_hist", P(flipped), P(tgt), 1, P(pred), P(hist), None, B, C_, h, w, H, W, stream())
     torch.cuda.synchronize()
     if safe.all():
         assert np.array_equal(hist.cpu().numpy().reshape(C_, C_), g["tail_hist2"].astype(np.int64))

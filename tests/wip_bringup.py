@@ -56,15 +56,22 @@ def stage_isolated(B, H, Wd):
 def end_to_end(tag):
     B, H, Wd = (int(v) for v in g[f"{tag}_shape"])
     eng = Engine(W, B, H, Wd)
+    st = O.SamState()
     for t in range(3):
         x, y = synth.synth_frame(t, B, H, Wd)
+        info = {}
+        with torch.no_grad():
+            op = O.forward_and_adapt(pt, st, torch.from_numpy(x), torch.from_numpy(y), CFG, info, bf16=True)
+            opred = O.upsample_probs(op, y.shape[-2:]).argmax(1).numpy()
         yd = torch.from_numpy(y).to(dev)
         probs = eng.forward_and_adapt(torch.from_numpy(x).to(dev), yd, CFG)
         eng.tail(yd)
         torch.cuda.synchronize()
         lg = eng.logits.cpu().numpy(); P = eng.P
         pl = eng.labels[:P].cpu().numpy().reshape(B, eng.h, eng.wd)
-        print(f"  {tag} t={t}: logits relerr {rel_err(lg, g[f'{tag}_{t}_logits']):.3e}  pseudo agree {(pl == g[f'{tag}_{t}_pseudo']).mean():.4f}"
+        print(f"  {tag} t={t} vs bf16-oracle: logits relerr {rel_err(lg, info['logits']):.3e} feat relerr {rel_err(eng.feat_nchw().cpu(), info['feature']):.3e} pseudo agree {(pl == info['pseudo'].numpy()).mean():.4f}"
+              f" probs maxabs {np.nanmax(np.abs(probs.cpu().numpy() - op.numpy())):.3e} pred agree {(eng.pred.cpu().numpy() == opred).mean():.5f} run relerr {rel_err(eng.run_proto.cpu(), st.run_proto):.3e}")
+        print(f"  {tag} t={t} vs fp32 ref  : logits relerr {rel_err(lg, g[f'{tag}_{t}_logits']):.3e}  pseudo agree {(pl == g[f'{tag}_{t}_pseudo']).mean():.4f}"
               f"  probs maxabs {np.nanmax(np.abs(probs.cpu().numpy() - g[f'{tag}_{t}_probs'])):.3e}  pred agree {(eng.pred.cpu().numpy() == g[f'{tag}_{t}_pred']).mean():.4f}"
               f"  run relerr {rel_err(eng.run_proto.cpu(), g[f'{tag}_{t}_run']):.3e} rflag eq {np.array_equal(eng.run_flag.cpu().numpy(), g[f'{tag}_{t}_rflag'])}"
               f"  hist L1 {np.abs(eng.hist.cpu().numpy().reshape(19,19) - g[f'{tag}_{t}_hist']).sum():.0f}/{g[f'{tag}_{t}_hist'].sum():.0f}")
