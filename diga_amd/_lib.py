@@ -64,6 +64,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise DigaError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(or `make -C diga_amd/csrc`). There is no CPU fallback.")
+    # torch ships its own libamdhip64: import it first so that this library binds to the SAME HIP runtime
+    # (two runtimes in one process -> "no ROCm-capable device is detected" on the second one).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

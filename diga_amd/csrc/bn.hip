@@ -7,18 +7,40 @@
 
 namespace {
 
-__global__ void bn_finalize_kernel(const float* __restrict__ slab, int ntiles, int C, double n_a, double n_b,
-                                   const float* __restrict__ rmean, const float* __restrict__ rvar,
-                                   const float* __restrict__ weight, const float* __restrict__ bias, float lam,
-                                   float eps, float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  // fixed tile order, fp64 accumulation of the fp32 per-tile partials -> deterministic
-  double s[4] = {0, 0, 0, 0};
-  for (int t = 0; t < ntiles; ++t) {
+// Block = 64 channels (lanes, coalesced slab reads) x FIN_PH tile phases (waves).  Phase w sums tiles
+// w, w+FIN_PH, ... in fp64; the phases are then combined through LDS in fixed order -> deterministic.
+constexpr int FIN_PH = 16;
+
+__device__ __forceinline__ void slab_phase_sums(const float* __restrict__ slab, int ntiles, int C, int c, int ph, double* s) {
+  s[0] = s[1] = s[2] = s[3] = 0;
+#pragma unroll 4
+  for (int t = ph; t < ntiles; t += FIN_PH) {
     const float* q = slab + (size_t)t * 4 * C + c;
 #pragma unroll
     for (int k = 0; k < 4; ++k) s[k] += (double)q[k * C];
+  }
+}
+
+__global__ __launch_bounds__(64 * FIN_PH) void bn_finalize_kernel(const float* __restrict__ slab, int ntiles, int C, double n_a,
+                                                                 double n_b, const float* __restrict__ rmean,
+                                                                 const float* __restrict__ rvar, const float* __restrict__ weight,
+                                                                 const float* __restrict__ bias, float lam, float eps,
+                                                                 float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double red[FIN_PH][4][64];
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double s[4];
+  if (c < C) slab_phase_sums(slab, ntiles, C, c, ph, s);
+  else s[0] = s[1] = s[2] = s[3] = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[ph][k][lane] = s[k];
+  __syncthreads();
+  if (ph != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double v = 0;
+    for (int w = 0; w < FIN_PH; ++w) v += red[w][k][lane];
+    s[k] = v;
   }
   const double K = (double)rmean[c];
   const double ma = s[0] / n_a;
@@ -39,12 +61,24 @@ __global__ void bn_finalize_kernel(const float* __restrict__ slab, int ntiles, i
   shift[c] = bias[c] - mean * sc;
 }
 
-__global__ void bn_reduce_slab_kernel(const float* __restrict__ slab, int ntiles, int C, float* __restrict__ sums) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // over 4*C
-  if (e >= 4 * C) return;
-  double s = 0;
-  for (int t = 0; t < ntiles; ++t) s += (double)slab[(size_t)t * 4 * C + e];
-  sums[e] = (float)s;
+__global__ __launch_bounds__(64 * FIN_PH) void bn_reduce_slab_kernel(const float* __restrict__ slab, int ntiles, int C,
+                                                                    float* __restrict__ sums) {
+  __shared__ double red[FIN_PH][4][64];
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double s[4];
+  if (c < C) slab_phase_sums(slab, ntiles, C, c, ph, s);
+  else s[0] = s[1] = s[2] = s[3] = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[ph][k][lane] = s[k];
+  __syncthreads();
+  if (ph != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double v = 0;
+    for (int w = 0; w < FIN_PH; ++w) v += red[w][k][lane];
+    sums[k * C + c] = (float)v;
+  }
 }
 
 // rows x C elementwise.  A thread owns one 8-channel octet (16 B) and walks rows, so its 8 scale/shift
@@ -197,7 +231,7 @@ extern "C" int diga_bn_finalize(const float* slab, int ntiles, int C, double n_a
                                 float* scale, float* shift, void* stream) {
   DIGA_CHECK_ARG(slab && running_mean && running_var && weight && bias && scale && shift, "diga_bn_finalize: NULL pointer");
   DIGA_CHECK_ARG(ntiles > 0 && C > 0 && n_a > 0 && n_b >= 0, "diga_bn_finalize: bad sizes ntiles=%d C=%d", ntiles, C);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, slab, ntiles, C, n_a, n_b,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64 * FIN_PH), 0, (hipStream_t)stream, slab, ntiles, C, n_a, n_b,
                      running_mean, running_var, weight, bias, lam, eps, scale, shift);
   DIGA_CHECK_LAUNCH("diga_bn_finalize");
   return DIGA_OK;
@@ -205,7 +239,7 @@ extern "C" int diga_bn_finalize(const float* slab, int ntiles, int C, double n_a
 
 extern "C" int diga_bn_reduce_slab(const float* slab, int ntiles, int C, float* sums, void* stream) {
   DIGA_CHECK_ARG(slab && sums && ntiles > 0 && C > 0, "diga_bn_reduce_slab: bad argument");
-  hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(cdiv(4 * C, 64)), dim3(64), 0, (hipStream_t)stream, slab, ntiles, C, sums);
+  hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(cdiv(C, 64)), dim3(64 * FIN_PH), 0, (hipStream_t)stream, slab, ntiles, C, sums);
   DIGA_CHECK_LAUNCH("diga_bn_reduce_slab");
   return DIGA_OK;
 }

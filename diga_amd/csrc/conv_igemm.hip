@@ -34,21 +34,33 @@ struct ConvKParams {
   int H, W, Cin, Ho, Wo, Cout, stride, ntaps;
   int M, K, cout_pad, split_row, nk_total, nk_per_split, mtiles, ntiles_n;
   unsigned in_bytes, wgt_bytes;
-  short dy[DIGA_MAX_TAPS], dx[DIGA_MAX_TAPS];
+  int dydx[DIGA_MAX_TAPS];   // (dy << 16) | (dx & 0xffff): 32-bit so that the uniform per-tap lookup is a scalar load
 };
+
+constexpr int conv_stages(int BM, int BN) { return (BM + BN) * 128 * 4 <= 131072 ? 4 : 3; }
+
+// 16 zero bytes: the source of every out-of-image / out-of-range 16-byte chunk of the gather
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 template <int BM, int BN, int WM, int WN, bool OUT_F32, bool STATS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
-  constexpr int A_CH = BM / 32, B_CH = BN / 32;      // 16-byte chunks per thread per K step
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-  static_assert(WM * WN == 4 && MT >= 1 && NT >= 1, "bad tile");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const sA = smem;                    // 2 x A_BYTES
-  unsigned char* const sB = smem + 2 * A_BYTES;      // 2 x B_BYTES
+  constexpr int A_CH = BM / 32, B_CH = BN / 32;      // LDS-DMA wave-instructions per wave per K step
+  constexpr int LPT = A_CH + B_CH;                   // loads per tile per wave (the vmcnt unit)
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int S = conv_stages(BM, BN);             // LDS ring depth; S-1 K steps of loads stay in flight
+  constexpr int D = S - 1;
+  static_assert(WM * WN == 4 && MT >= 1 && NT >= 1 && S >= 2 && S <= 4, "bad tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ONLY LDS object (cdna guide 5, trap 4a)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hh = lane >> 5;
 
@@ -63,23 +75,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   const int m0 = mtile * BM, n0 = ntile * BN;
   const int ks_begin = blockIdx.y * p.nk_per_split;
   const int ks_end = min(ks_begin + p.nk_per_split, p.nk_total);
+  const int nt = ks_end - ks_begin;
 
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
-
-  // ---- per-thread gather state: rows are fixed for the whole K loop
-  const int kc = tid & 7, r0 = tid >> 3;
+  // ---- gather state.  One LDS-DMA wave-instruction (global_load_lds_dwordx4) writes 1 KiB = 8 tile rows of
+  // 128 B, lane l -> row (l>>3), 16-byte slot (l&7).  The LDS image is lane-linear, so the XOR swizzle is
+  // applied on the SOURCE: slot s of row r holds channel chunk s ^ ((r>>1)&7) (cdna guide 5.4 rule 21).
+  // Wave w owns row groups w, w+4, ... (rows 8w + 32i + (l>>3)); those rows are fixed for the whole K loop.
+  const int lrow = 8 * wave + (lane >> 3);
+  const int cch = (lane & 7) ^ ((lrow >> 1) & 7);    // channel chunk this lane fetches ((row>>1)&7 is i-invariant)
+  const unsigned short* const in = reinterpret_cast<const unsigned short*>(p.in);
+  const unsigned short* const wgt = reinterpret_cast<const unsigned short*>(p.wgt);
+  const unsigned short* const zero = reinterpret_cast<const unsigned short*>(g_zero16);
   int pixoff[A_CH], ih0[A_CH], iw0[A_CH];
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
-    const int m = m0 + r0 + 32 * i;
+    const int m = m0 + lrow + 32 * i;
     if (m < p.M) {
       const int hw = p.Ho * p.Wo;
       const int n = m / hw, rem = m - n * hw;
       const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
       ih0[i] = oh * p.stride;
       iw0[i] = ow * p.stride;
-      pixoff[i] = ((n * p.H + ih0[i]) * p.W + iw0[i]) * p.Cin;
+      pixoff[i] = ((n * p.H + ih0[i]) * p.W + iw0[i]) * p.Cin + cch * 8;
     } else {
       ih0[i] = -100000;  // every tap lands outside the image -> zeros
       iw0[i] = 0;
@@ -88,31 +105,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   }
   int wrow_off[B_CH];
 #pragma unroll
-  for (int j = 0; j < B_CH; ++j) wrow_off[j] = (n0 + r0 + 32 * j) * p.K + kc * 8;
+  for (int j = 0; j < B_CH; ++j) wrow_off[j] = (n0 + lrow + 32 * j) * p.K + cch * 8;
 
-  u32x4 ra[A_CH], rb[B_CH];
-  auto load_tiles = [&](int ks) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  auto issue_tile = [&](int ks, int stage) {
     const int kk = ks * 64;
     const int tap = kk / p.Cin, c0 = kk - tap * p.Cin;
-    const int dy = p.dy[tap], dx = p.dx[tap];
-    const int tapoff = (dy * p.W + dx) * p.Cin + c0 + kc * 8;
+    const int dd = p.dydx[tap];
+    const int dy = dd >> 16, dx = (int)(short)(dd & 0xffff);
+    const int tapoff = (dy * p.W + dx) * p.Cin + c0;
+    unsigned char* const dA = smem + stage * STAGE_BYTES + wave * 1024;
+    unsigned char* const dB = dA + A_BYTES;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const bool ok = (unsigned)(ih0[i] + dy) < (unsigned)p.H && (unsigned)(iw0[i] + dx) < (unsigned)p.W;
-      const unsigned voff = ok ? (unsigned)(pixoff[i] + tapoff) * 2u : 0x7ffffff0u;
-      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff, 0, 0);
+      const unsigned short* src = ok ? in + (pixoff[i] + tapoff) : zero;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(dA + i * 4096), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_CH; ++j)
-      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (unsigned)(wrow_off[j] + kk) * 2u, 0, 0);
-  };
-  const int st_swz = (r0 >> 1) & 7;                  // (row>>1)&7 is the same for row and row+32*i
-  const int st_off = r0 * 128 + ((kc ^ st_swz) << 4);
-  auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(sA + buf * A_BYTES + st_off + i * 4096) = ra[i];
-#pragma unroll
-    for (int j = 0; j < B_CH; ++j) *reinterpret_cast<u32x4*>(sB + buf * B_BYTES + st_off + j * 4096) = rb[j];
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(wgt + (wrow_off[j] + kk)), (lds_ptr)(dB + j * 4096), 16, 0, 0);
   };
 
   f32x16 acc[MT][NT];
@@ -124,19 +137,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int fr_swz = (l31 >> 1) & 7;
-  const int fa_row = (wm * WTM + l31) * 128, fb_row = (wn * WTN + l31) * 128;
+  const int fa_row = (wm * WTM + l31) * 128, fb_row = A_BYTES + (wn * WTN + l31) * 128;
 
-  if (ks_begin < ks_end) {
-    load_tiles(ks_begin);
-    store_tiles(0);
-  }
-  __syncthreads();
-  int cur = 0;
-  for (int ks = ks_begin; ks < ks_end; ++ks) {
-    const bool more = ks + 1 < ks_end;
-    if (more) load_tiles(ks + 1);
-    const unsigned char* bA = sA + cur * A_BYTES + fa_row;
-    const unsigned char* bB = sB + cur * B_BYTES + fb_row;
+  // ---- K loop: S-deep LDS ring filled by LDS-DMA, one raw barrier per K step, counted vmcnt so that up to
+  // D = S-1 tiles stay in flight across the barrier (never __syncthreads(): its fence drains vmcnt to 0).
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nt) issue_tile(ks_begin + s, s);
+  int stage = 0, fill = D % S;
+  for (int t = 0; t < nt; ++t) {
+    // tile t must have landed: leave at most min(D-1, nt-1-t) younger tiles of THIS wave outstanding
+    const int younger = min(D - 1, nt - 1 - t);
+    if (younger >= 2) wait_vmcnt<(D >= 3 ? 2 : 0) * LPT>();
+    else if (younger == 1) wait_vmcnt<(D >= 2 ? 1 : 0) * LPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();       // every wave's part of tile t is in LDS; everyone is done reading tile t-1
+    if (t + D < nt) issue_tile(ks_begin + t + D, fill);   // refills the buffer tile t-1 was read from
+    const unsigned char* bA = smem + stage * STAGE_BYTES + fa_row;
+    const unsigned char* bB = smem + stage * STAGE_BYTES + fb_row;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int coff = ((2 * s + hh) ^ fr_swz) << 4;
@@ -151,10 +169,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
         for (int b = 0; b < NT; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
-    if (more) store_tiles(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    stage = stage + 1 == S ? 0 : stage + 1;
+    fill = fill + 1 == S ? 0 : fill + 1;
   }
+  __syncthreads();                      // all LDS reads done: the epilogue reuses the ring
 
   // ------------------------------------------------------------------ epilogue
   // accumulator element r of tile (a,b): row = wm*WTM + a*32 + (r&3) + 8*(r>>2) + 4*hh, col = wn*WTN + b*32 + l31
@@ -284,10 +302,17 @@ int auto_tile(const diga_conv_desc* d) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const ConvKParams& p, int splitk, bool out_f32, bool stats, hipStream_t st) {
-  constexpr int main_bytes = 2 * (BM + BN) * 128;
+  constexpr int main_bytes = conv_stages(BM, BN) * (BM + BN) * 128;
   constexpr int epi_bytes = WM * 4 * BN * 4 > BM * BN * 2 ? WM * 4 * BN * 4 : BM * BN * 2;
   constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   dim3 grid(p.mtiles * p.ntiles_n, splitk), block(256);
+  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
   if (out_f32 && !stats)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, false>), grid, block, smem, st, p);
   else if (!out_f32 && stats)
@@ -357,8 +382,8 @@ extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, con
   p.in_bytes = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * 2);
   p.wgt_bytes = (unsigned)((int64_t)d->cout_pad * p.K * 2);
   for (int i = 0; i < DIGA_MAX_TAPS; ++i) {
-    p.dy[i] = i < d->ntaps ? d->dy[i] : 0;
-    p.dx[i] = i < d->ntaps ? d->dx[i] : 0;
+    const int dy = i < d->ntaps ? d->dy[i] : 0, dx = i < d->ntaps ? d->dx[i] : 0;
+    p.dydx[i] = (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu));
   }
   hipStream_t st = (hipStream_t)stream;
   const bool f32 = d->out_f32 != 0, stats = stat_slab != nullptr;

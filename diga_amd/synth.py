@@ -64,7 +64,7 @@ def bn_names():
     return out
 
 
-HEAD_STD = 0.25   # head weight std: tuned so that ~30-60 % of pixels clear the 0.9 confidence bar
+HEAD_STD = 0.05   # head weight std: tuned so that ~30-60 % of pixels clear the 0.9 confidence bar
 
 
 def synth_params(seed: int = 0, num_classes: int = NUM_CLASSES, bn_stats: dict | str | None = "auto") -> dict:
@@ -92,18 +92,17 @@ def synth_params(seed: int = 0, num_classes: int = NUM_CLASSES, bn_stats: dict |
             bn_stats = {k: z[k] for k in z.files}
     for name, c in bn_names():
         r = _rng(seed, name)
-        # A random BN+ReLU stack is chaotic at initialisation (mean-centred ReLU decorrelates inputs
+        # A random BN+ReLU stack is chaotic at initialisation (mean-centred ReLUs decorrelate their inputs
         # ~1.5x per layer), which would amplify bf16 storage rounding ~300x over the 33 blocks and make
-        # end-to-end comparisons meaningless.  Trained nets are not like that; keep the synthetic one tame:
-        # small residual-branch gains (bn3 / downsample) and mostly-open ReLUs inside the branch
-        # (beta/gamma ~ 2.5) give a ~4x end-to-end perturbation gain.
-        last = name.endswith("bn3") or name.endswith("downsample.1")
-        lo, hi = (0.05, 0.10) if last else (0.3, 0.5)
-        p[name + ".weight"] = r.uniform(lo, hi, c).astype(np.float32)
-        if last:
-            p[name + ".bias"] = (r.standard_normal(c) * 0.05).astype(np.float32)
+        # end-to-end comparisons meaningless.  Trained nets are not like that; keep the synthetic one tame
+        # the way trained ResNets are: the residual stream is dominated by the (linear) downsample path
+        # (gamma ~ 1) and every block adds a small correction (bn3 gamma ~ 0.05-0.1).
+        if name.endswith("bn3"):
+            p[name + ".weight"] = r.uniform(0.05, 0.10, c).astype(np.float32)
+            p[name + ".bias"] = (r.standard_normal(c) * 0.02).astype(np.float32)
         else:
-            p[name + ".bias"] = (1.0 + r.standard_normal(c) * 0.3).astype(np.float32)
+            p[name + ".weight"] = r.uniform(0.8, 1.2, c).astype(np.float32)
+            p[name + ".bias"] = (r.standard_normal(c) * 0.1).astype(np.float32)
         if bn_stats is not None:
             p[name + ".running_mean"] = np.asarray(bn_stats[name + ".running_mean"], np.float32)
             p[name + ".running_var"] = np.asarray(bn_stats[name + ".running_var"], np.float32)

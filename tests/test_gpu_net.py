@@ -9,8 +9,10 @@ Three levels (hard part 1):
     the north star* (bf16 MFMA), not a kernel error, so this level is stated as agreement rates; the
     same bounds hold for the oracle's own bf16-storage emulation (O.net_forward_feat_bf16), i.e. they are
     the bf16 noise floor of this 101-layer net, not slack for the kernels:
-        logits  <= 6e-2 of the logit range, pseudo labels >= 95 % equal, final arg-max >= 93 % equal,
-        running-prototype flags identical, mIoU-19/16/13 within +-0.1 (the north-star bar).
+        per frame, the GPU path may be at most 1.5x as far from the reference as the oracle's bf16-storage
+        emulation is (tests/golden/bf16_floor.json, made by tests/golden/make_bf16_floor.py: logits ~1 % of
+        the logit range, pseudo labels ~98-99 % equal, final arg-max 92-99.6 % equal), the running-prototype
+        flags must be identical and mIoU-19/16/13 within +-0.1 (the north-star bar).
  3. run-to-run determinism: bit-identical outputs (no atomics on floats anywhere in the path).
 """
 import functools
@@ -102,6 +104,27 @@ def test_stage_isolated_whole_net(weights, synth_params_np, B, H, W):
     assert np.array_equal(eng.labels[:eng.P].cpu().numpy().reshape(pm.shape)[safe], O.pseudo_labels(lg, 0.9).numpy()[safe])
 
 
+def _floor():
+    import json
+    import os
+    from conftest import GOLD
+    with open(os.path.join(GOLD, "bf16_floor.json")) as f:
+        return json.load(f)
+
+
+def _check_against_floor(stats, floor_frames):
+    """The GPU's rounding noise is another draw from the same distribution as the emulation's, and a 9x17 grid
+    is only 153 pixels, so the per-frame floor is itself noisy: bound every frame by 1.5x the WORST floor over
+    the whole fixture set (pooled), not by its own frame's floor."""
+    fl_all = [f for tag in _floor().values() for f in tag["frames"]]
+    worst = {k: (max if k.endswith("err") else min)(f[k] for f in fl_all) for k in ("logit_err", "pseudo_agree", "pred_agree")}
+    for s in stats:
+        assert s["logit_err"] <= 1.5 * worst["logit_err"], (s, worst)
+        assert s["pseudo_agree"] >= 1 - 1.5 * (1 - worst["pseudo_agree"]), (s, worst)
+        assert s["pred_agree"] >= 1 - 1.5 * (1 - worst["pred_agree"]), (s, worst)
+        assert s["rflag_equal"], s
+
+
 def _run_gold_sequence(m, g, tag, B, H, W, nframes):
     if hasattr(m, "classifier_running_proto"):
         del m.classifier_running_proto
@@ -136,8 +159,7 @@ def test_end_to_end_vs_reference_small(diga, gold_small, tag):
     B, H, W = (int(v) for v in g[f"{tag}_shape"])
     stats, mious = _run_gold_sequence(diga, g, tag, B, H, W, 3)
     print(tag, stats, mious, g[f"{tag}_miou"])
-    for s in stats:
-        assert s["logit_err"] <= 6e-2 and s["pseudo_agree"] >= 0.95 and s["pred_agree"] >= 0.93 and s["rflag_equal"], s
+    _check_against_floor(stats, _floor()[tag]["frames"])
     assert np.abs(np.array(mious) - g[f"{tag}_miou"]).max() <= 0.1          # north-star bar: mIoU within +-0.1
 
 
@@ -145,8 +167,7 @@ def test_end_to_end_vs_reference_full_res(diga, gold_full):
     """Two 1024x512 frames (prototype seeding branch, then the EMA branch) against the reference."""
     stats, mious = _run_gold_sequence(diga, gold_full, "", 1, 512, 1024, 2)
     print(stats, mious, gold_full["miou"])
-    for s in stats:
-        assert s["logit_err"] <= 6e-2 and s["pseudo_agree"] >= 0.95 and s["pred_agree"] >= 0.93 and s["rflag_equal"], s
+    _check_against_floor(stats, _floor()["full"]["frames"])
     assert np.abs(np.array(mious) - gold_full["miou"]).max() <= 0.1
 
 
