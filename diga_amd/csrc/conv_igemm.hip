@@ -37,8 +37,6 @@ struct ConvKParams {
   int dydx[DIGA_MAX_TAPS];   // (dy << 16) | (dx & 0xffff): 32-bit so that the uniform per-tap lookup is a scalar load
 };
 
-constexpr int conv_stages(int BM, int BN) { return (BM + BN) * 128 * 4 <= 131072 ? 4 : 3; }
-
 // 16 zero bytes: the source of every out-of-image / out-of-range 16-byte chunk of the gather
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
 
@@ -47,14 +45,14 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, bool OUT_F32, bool STATS>
+template <int BM, int BN, int WM, int WN, int S, bool OUT_F32, bool STATS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
   constexpr int A_CH = BM / 32, B_CH = BN / 32;      // LDS-DMA wave-instructions per wave per K step
   constexpr int LPT = A_CH + B_CH;                   // loads per tile per wave (the vmcnt unit)
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int S = conv_stages(BM, BN);             // LDS ring depth; S-1 K steps of loads stay in flight
+  // S = LDS ring depth; S-1 K steps of loads stay in flight
   constexpr int D = S - 1;
   static_assert(WM * WN == 4 && MT >= 1 && NT >= 1 && S >= 2 && S <= 4, "bad tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ONLY LDS object (cdna guide 5, trap 4a)
@@ -280,10 +278,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 }
 
 struct TileCfg {
-  int id, BM, BN;
+  int id, BM, BN, S;
 };
-// id 1: 128x128, 2: 128x64, 3: 64x64, 4: 64x128, 5: 128x32 (head)
-const TileCfg kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {4, 64, 128}, {5, 128, 32}};
+// id = shape + 10*(4 - ring depth).  shape 1: 128x128, 2: 128x64, 3: 64x64, 4: 64x128, 5: 128x32 (head).
+// LDS per block = S*(BM+BN)*128 B, so the ring depth also sets how many blocks share a CU (160 KiB).
+const TileCfg kTiles[] = {{1, 128, 128, 4}, {11, 128, 128, 3}, {21, 128, 128, 2}, {2, 128, 64, 4}, {12, 128, 64, 3}, {22, 128, 64, 2},
+                          {3, 64, 64, 4},   {13, 64, 64, 3},   {23, 64, 64, 2},   {4, 64, 128, 4}, {14, 64, 128, 3}, {24, 64, 128, 2},
+                          {5, 128, 32, 4},  {15, 128, 32, 3},  {25, 128, 32, 2}};
 
 const TileCfg* find_tile(int id) {
   for (const auto& t : kTiles)
@@ -293,32 +294,35 @@ const TileCfg* find_tile(int id) {
 
 int auto_tile(const diga_conv_desc* d) {
   const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
-  if (d->cout_pad % 64 != 0) return 5;
+  // Measured on MI355X over the net's real shapes (tests/bench_conv.py, profiles/r1_conv_tile_sweep.log): at
+  // M = 8385..33153 rows the loop is bound by what one CU can pull from L2 (~60-70 GB/s), not by MFMA issue, and
+  // several small co-resident blocks per CU (2-deep ring, 32-48 KB LDS) beat one big block with a deep ring.
+  if (d->cout_pad % 64 != 0) return 25;
   auto blocks = [&](int bm, int bn) { return (int64_t)cdiv(M, bm) * cdiv(d->cout_pad, bn) * d->splitk; };
-  if (d->cout_pad % 128 == 0 && blocks(128, 128) >= 440) return 1;
-  if (blocks(128, 64) >= 220) return 2;
-  return 3;
+  if (d->cout_pad % 128 == 0 && blocks(128, 128) >= 2048) return 21;   // big batches: 128x128, 2 blocks / CU
+  if (d->cout_pad % 128 == 0 && d->cout_pad >= 512) return 24;         // 64x128
+  return 23;                                                           // 64x64
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int S>
 int launch_cfg(const ConvKParams& p, int splitk, bool out_f32, bool stats, hipStream_t st) {
-  constexpr int main_bytes = conv_stages(BM, BN) * (BM + BN) * 128;
+  constexpr int main_bytes = S * (BM + BN) * 128;
   constexpr int epi_bytes = WM * 4 * BN * 4 > BM * BN * 2 ? WM * 4 * BN * 4 : BM * BN * 2;
   constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   dim3 grid(p.mtiles * p.ntiles_n, splitk), block(256);
   static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   if (out_f32 && !stats)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, false>), grid, block, smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, true, false>), grid, block, smem, st, p);
   else if (!out_f32 && stats)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, true>), grid, block, smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, false, true>), grid, block, smem, st, p);
   else if (!out_f32 && !stats)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, false>), grid, block, smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, false, false>), grid, block, smem, st, p);
   else {
     diga_set_error("diga_conv_igemm_bf16: statistics with fp32 split-K output are not supported");
     return DIGA_EINVAL;
@@ -388,13 +392,18 @@ extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, con
   hipStream_t st = (hipStream_t)stream;
   const bool f32 = d->out_f32 != 0, stats = stat_slab != nullptr;
   int e = DIGA_OK;
+#define DIGA_TILE_CASES(base, BM, BN, WM, WN)                                                   \
+  case base: e = launch_cfg<BM, BN, WM, WN, 4>(p, d->splitk, f32, stats, st); break;          \
+  case base + 10: e = launch_cfg<BM, BN, WM, WN, 3>(p, d->splitk, f32, stats, st); break;     \
+  case base + 20: e = launch_cfg<BM, BN, WM, WN, 2>(p, d->splitk, f32, stats, st); break;
   switch (t->id) {
-    case 1: e = launch_cfg<128, 128, 2, 2>(p, d->splitk, f32, stats, st); break;
-    case 2: e = launch_cfg<128, 64, 2, 2>(p, d->splitk, f32, stats, st); break;
-    case 3: e = launch_cfg<64, 64, 2, 2>(p, d->splitk, f32, stats, st); break;
-    case 4: e = launch_cfg<64, 128, 2, 2>(p, d->splitk, f32, stats, st); break;
-    case 5: e = launch_cfg<128, 32, 4, 1>(p, d->splitk, f32, stats, st); break;
+    DIGA_TILE_CASES(1, 128, 128, 2, 2)
+    DIGA_TILE_CASES(2, 128, 64, 2, 2)
+    DIGA_TILE_CASES(3, 64, 64, 2, 2)
+    DIGA_TILE_CASES(4, 64, 128, 2, 2)
+    DIGA_TILE_CASES(5, 128, 32, 4, 1)
   }
+#undef DIGA_TILE_CASES
   if (e) return e;
   DIGA_CHECK_LAUNCH("diga_conv_igemm_bf16");
   return DIGA_OK;

@@ -191,11 +191,8 @@ class Engine:
     # ------------------------------------------------------------------ helpers
     def _groups(self, rows_per_sample):
         """(split_row, n_a, n_b) of the reference's half_first rule (ttda:313-320) for the *global* batch."""
-        gb = self.B * self.world
-        if gb == 1:
-            return self.B * rows_per_sample, float(rows_per_sample), 0.0
-        split = rows_per_sample if self.rank == 0 else 0
-        return split, float(rows_per_sample), float((gb - 1) * rows_per_sample)
+        from .dist import group_plan
+        return group_plan(self.rank, self.world, self.B, rows_per_sample)
 
     def _finalize(self, bn: BNP, ntiles, rows_per_sample):
         _, n_a, n_b = self._groups(rows_per_sample)
@@ -325,7 +322,7 @@ class Engine:
                 d.dy[br * 9 + t], d.dx[br * 9 + t] = (t // 3 - 1) * dil, (t % 3 - 1) * dil
         d.cout_pad = self.w.head_cpad
         d.split_row = self.P
-        d.splitk, d.out_f32, d.tile = self.head_splitk, 1, 5
+        d.splitk, d.out_f32, d.tile = self.head_splitk, 1, 0
         ev = self._ev_start()
         call("diga_conv_igemm_bf16", C.byref(d), _p(feat), _p(hw), _p(self.head_part), None, None, _stream())
         self._ev_end(ev, "head", 2 * self.P * self.C * cin * 18)

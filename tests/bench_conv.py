@@ -1,0 +1,76 @@
+"""Tile / ring-depth sweep of diga_conv_igemm_bf16 over the network's real conv shapes (not a pytest file).
+
+    python tests/bench_conv.py [--shapes l3] [--tiles 2,12,22] [--reps 20]
+Prints, per shape and tile id, the mean launch time (HIP events over `reps` back-to-back launches) and TFLOP/s.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+
+from gpu_util import DEV, P, call, conv_desc, stream
+
+# name: (H, W, Cin, Cout, stride, k3, dil)
+SHAPES = {
+    "l1.c1a": (129, 257, 64, 64, 1, False, 1), "l1.c1": (129, 257, 256, 64, 1, False, 1), "l1.c2": (129, 257, 64, 64, 1, True, 1),
+    "l1.c3": (129, 257, 64, 256, 1, False, 1),
+    "l2.c1a": (129, 257, 256, 128, 2, False, 1), "l2.c1": (65, 129, 512, 128, 1, False, 1), "l2.c2": (65, 129, 128, 128, 1, True, 1),
+    "l2.c3": (65, 129, 128, 512, 1, False, 1), "l2.ds": (129, 257, 256, 512, 2, False, 1),
+    "l3.c1a": (65, 129, 512, 256, 1, False, 1), "l3.c1": (65, 129, 1024, 256, 1, False, 1), "l3.c2": (65, 129, 256, 256, 1, True, 2),
+    "l3.c3": (65, 129, 256, 1024, 1, False, 1), "l3.ds": (65, 129, 512, 1024, 1, False, 1),
+    "l4.c1a": (65, 129, 1024, 512, 1, False, 1), "l4.c1": (65, 129, 2048, 512, 1, False, 1), "l4.c2": (65, 129, 512, 512, 1, True, 4),
+    "l4.c3": (65, 129, 512, 2048, 1, False, 1), "l4.ds": (65, 129, 1024, 2048, 1, False, 1),
+}
+ALL_TILES = [1, 11, 21, 2, 12, 22, 3, 13, 23, 4, 14, 24]
+
+
+def run(name, tiles, reps, B=1):
+    H, W, Cin, Cout, stride, k3, dil = SHAPES[name]
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(B * H * W * Cin, generator=g)).to(torch.bfloat16).to(DEV)
+    taps = 9 if k3 else 1
+    w = (torch.randn(Cout * taps * Cin, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    shift = torch.zeros(Cout, dtype=torch.float32, device=DEV)
+    res = []
+    for tile in tiles:
+        d = conv_desc(B, H, W, Cin, Cout, stride, k3, dil, tile=tile)
+        bn = {1: 128, 2: 64, 3: 64, 4: 128, 5: 32}[tile % 10]
+        if Cout % bn:
+            continue
+        M = B * d.Ho * d.Wo
+        nt = call("diga_conv_num_mtiles", C.byref(d))
+        out = torch.empty(M * Cout, dtype=torch.bfloat16, device=DEV)
+        slab = torch.empty(nt * 4 * Cout, dtype=torch.float32, device=DEV)
+        for _ in range(3):
+            call("diga_conv_igemm_bf16", C.byref(d), P(x), P(w), P(out), P(slab), P(shift), stream())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call("diga_conv_igemm_bf16", C.byref(d), P(x), P(w), P(out), P(slab), P(shift), stream())
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        fl = 2.0 * M * Cout * Cin * taps
+        bm = {1: 128, 2: 128, 3: 64, 4: 64, 5: 128}[tile % 10]
+        res.append((tile, us, fl / us / 1e6, nt * (Cout // bn)))
+    best = min(res, key=lambda r: r[1])
+    print(f"{name:7s} M={B * d.Ho * d.Wo:6d} K={taps * Cin:5d} N={Cout:5d} {fl / 1e9:6.2f} GF | " +
+          " ".join(f"t{t}:{us:6.1f}us/{tf:4.0f}TF/{nb}b" for t, us, tf, nb in res) + f" | best t{best[0]} {best[1]:.1f}us {best[2]:.0f}TF", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="")
+    ap.add_argument("--tiles", default="")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1)
+    a = ap.parse_args()
+    tiles = [int(t) for t in a.tiles.split(",")] if a.tiles else ALL_TILES
+    for n in SHAPES:
+        if a.shapes and not any(n.startswith(s) for s in a.shapes.split(",")):
+            continue
+        run(n, tiles, a.reps, a.batch)

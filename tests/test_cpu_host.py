@@ -1,0 +1,208 @@
+"""CPU-only tests (-m "not gpu"): the C-ABI library loads and exports every symbol include/diga_hip.h declares
+(no compute calls without a GPU), the host-side planning logic, argument validation that needs no device, the
+reference-API mirror's state-dict / checkpoint behaviour, and the multi-GPU sharding protocol over gloo."""
+import ctypes as C
+import functools
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from diga_amd import _lib, synth
+from diga_amd import ttda_module as T
+from diga_amd.engine import feature_grid, pack_conv_weight, pool_out
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "diga_hip.h")).read()
+    declared = set(re.findall(r"\b(diga_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/diga_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.diga_version() >= 100
+
+
+def test_conv_desc_layout_matches_header():
+    # int32 x9, int16 x18 x2, int32 x5
+    assert C.sizeof(_lib.ConvDesc) == 9 * 4 + 2 * 18 * 2 + 5 * 4
+
+
+def test_argument_validation_needs_no_gpu():
+    d = _lib.ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 1, 9, 17, 48, 9, 17, 64
+    d.stride, d.ntaps, d.cout_pad, d.split_row, d.splitk = 1, 1, 64, 153, 1
+    with pytest.raises(_lib.DigaError, match="Cin=48"):
+        _lib.call("diga_conv_num_mtiles", C.byref(d))
+    d.Cin = 64
+    assert _lib.call("diga_conv_num_mtiles", C.byref(d)) == 3          # 153 rows / 64
+    d.splitk = 2                                                        # split-K needs fp32 partial output
+    with pytest.raises(_lib.DigaError, match="splitk"):
+        _lib.call("diga_conv_num_mtiles", C.byref(d))
+    assert _lib.call("diga_stem_conv7x7s2", None, None, None, None, None, 1, 512, 1024, 0, None) == 64 * 8
+    assert _lib.call("diga_proto_pool_work_bytes", 2, 8385, 19, 2048) > 0
+    with pytest.raises(_lib.DigaError):
+        _lib.call("diga_bn_apply", None, None, None, None, None, None, None, 10, 64, 1, None)
+
+
+def test_feature_grid_matches_reference_shapes():
+    # 1024x512 -> 65x129, 2048x1024 -> 129x257, 1280x720 -> 91x161, 960x540 -> 68x121
+    assert feature_grid(512, 1024)[2] == (65, 129)
+    assert feature_grid(1024, 2048)[2] == (129, 257)
+    assert feature_grid(720, 1280)[2] == (91, 161)
+    assert feature_grid(540, 960)[2] == (68, 121)
+    for L in range(2, 300):
+        x = torch.zeros(1, 1, L, 4)
+        assert pool_out(L) == torch.nn.functional.max_pool2d(x, 3, 2, 1, ceil_mode=True).shape[2]
+
+
+def test_weight_packing_layout():
+    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3)
+    p = pack_conv_weight(w, cout_pad=4)
+    assert p.shape == (4, 27) and p.dtype == torch.bfloat16
+    assert float(p[1, (1 * 3 + 2) * 3 + 0]) == float(w[1, 0, 1, 2])   # [co][kh][kw][ci]
+    assert p[2:].abs().sum() == 0
+
+
+def _diga():
+    return T.DIGA(net=functools.partial(T.DeepLabv2AdaptSeg, multi_level=True, restore_from=None),
+                  dataset_info=dict(num_classes=19, image_size=(321, 321), test_list=[0, 1], class_names=[str(i) for i in range(19)]),
+                  cfg=dict(bn_lambda=0.8, proto_lambda=0.8, fusion_lambda=0.8, confidence_threshold=0.9, proto_rho=0.1))
+
+
+def test_module_tree_has_reference_state_dict_keys():
+    m = _diga()
+    keys = set(m.net.state_dict().keys())
+    want = set(synth.synth_params(0, bn_stats=None).keys())
+    assert want <= keys
+    assert {k for k in keys - want} == {n + ".lambda_" for n, _ in synth.bn_names()}
+    assert len(m.test_acc) == 2 and not hasattr(m, "classifier_running_proto")
+    bns = [mod for mod in m.net.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+    assert len(bns) == 104 and all(isinstance(b, T.SIFABatchNorm2dTrainable) for b in bns)
+    assert all(abs(float(b.lambda_) - 0.8) < 1e-7 for b in bns)        # _configure_bn_running_stats (ttda:1808-1812)
+    with pytest.raises(ValueError, match="No wandb logger"):
+        m.wandb
+
+
+def test_checkpoint_restore_dispatch_and_remap(tmp_path):
+    """restore(): name dispatch + layer5.* -> layer6.* remap + ValueError cases (ttda:948-1016), as pinned by the
+    reference run recorded in tests/golden/loader.json."""
+    import hashlib
+    import json
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "loader.json")))
+    p = synth.synth_params(0)
+    saved = {}
+    for k, v in p.items():
+        if k.startswith("layer5."):
+            continue
+        saved[("layer5." + k.split(".", 1)[1]) if k.startswith("layer6.") else k] = torch.from_numpy(v)
+    path = str(tmp_path / "synth_GTA5_baseline.pth")
+    torch.save(saved, path)
+    net = T.DeepLabv2AdaptSeg(num_classes=19, multi_level=True, restore_from=path)
+    sd = net.state_dict()
+    for k, h in rec["checks"].items():
+        assert hashlib.sha256(np.ascontiguousarray(sd[k].numpy()).tobytes()).hexdigest() == h, k
+    bad = dict(saved)
+    bad["mystery.weight"] = torch.zeros(1)
+    torch.save(bad, str(tmp_path / "bad_baseline.pth"))
+    with pytest.raises(ValueError, match=rec["bad_key_error"]):
+        T.DeepLabv2AdaptSeg(restore_from=str(tmp_path / "bad_baseline.pth"))
+    torch.save(saved, str(tmp_path / "unknown_name.pth"))
+    with pytest.raises(ValueError, match=rec["unknown_name_error"]):
+        T.DeepLabv2AdaptSeg(restore_from=str(tmp_path / "unknown_name.pth"))
+
+
+def test_no_cpu_fallback():
+    m = _diga()
+    x = torch.zeros(1, 3, 65, 129)
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.DigaError):
+            m.net(x, feat=True)
+        with pytest.raises(_lib.DigaError):
+            T.SIFABatchNorm2dTrainable(8).eval()(torch.zeros(1, 8, 4, 4))
+
+
+def test_metric_miou_subsets():
+    met = T.SegmentationMetric(19)
+    rng = np.random.default_rng(0)
+    met.add_counts(torch.from_numpy(rng.integers(0, 50, (19, 19))))
+    from oracle import diga_oracle as O
+    for kind in ("default", "16", "13"):
+        assert abs(float(met.compute_iou(kind)) - float(O.miou(met.hist, kind))) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-GPU protocol over gloo, world_size 2: each rank holds one frame; the per-channel
+# shifted sums of the two half_first groups are all-reduced and finalised exactly as diga_bn_finalize does;
+# the result must equal the reference's B = 2 statistic (oracle.dam_current_stats).  Prototype sums likewise.
+# ------------------------------------------------------------------------------------------------
+def _dist_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from diga_amd.dist import group_plan
+
+    def finalize_from_sums(s, n_a, n_b, rm, rv, wt, bs, lam, eps):      # the arithmetic of diga_bn_finalize (bn.hip)
+        s = s.double()
+        ma = s[0] / n_a
+        mean_cur, var_cur = (rm.double() + ma).float(), (s[1] / n_a - ma * ma).float()
+        if n_b > 0:
+            mb = s[2] / n_b
+            mean_cur = (mean_cur + (rm.double() + mb).float()) / 2
+            var_cur = (var_cur + (s[3] / n_b - mb * mb).float()) / 2
+        lam = torch.tensor(lam, dtype=torch.float32)
+        mean, var = lam * rm + (1 - lam) * mean_cur, lam * rv + (1 - lam) * var_cur
+        sc = wt / torch.sqrt(var + eps)
+        return sc, bs - mean * sc
+    from oracle import diga_oracle as O
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    B, Cc, H, W = world, 16, 7, 9
+    x = torch.randn(B, Cc, H, W, generator=g) * 2 + 1
+    rm, rv = torch.randn(Cc, generator=g), torch.rand(Cc, generator=g) + 0.5
+    wt, bs = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    mine = x[rank:rank + 1]
+    split, n_a, n_b = group_plan(rank, world, 1, H * W)
+    rows = mine.permute(0, 2, 3, 1).reshape(-1, Cc).double() - rm.double()
+    sums = torch.zeros(4, Cc, dtype=torch.float64)
+    sums[0], sums[1] = rows[:split].sum(0), (rows[:split] ** 2).sum(0)
+    sums[2], sums[3] = rows[split:].sum(0), (rows[split:] ** 2).sum(0)
+    sums = sums.float()
+    dist.all_reduce(sums)
+    sc, sh = finalize_from_sums(sums, n_a, n_b, rm, rv, wt, bs, 0.8, 1e-5)
+    y = mine * sc[None, :, None, None] + sh[None, :, None, None]
+    ref = O.dam_bn(x, rm, rv, wt, bs, 0.8)[rank:rank + 1]
+    err = float((y - ref).abs().max() / ref.abs().max())
+    # prototype sufficient statistics
+    feat = torch.randn(B, 8, H, W, generator=g).relu()
+    lab = torch.randint(0, 5, (B, H, W), generator=g)
+    f = feat[rank].permute(1, 2, 0).reshape(-1, 8)
+    s = torch.zeros(19, 8)
+    c = torch.zeros(19, dtype=torch.int32)
+    for k in range(19):
+        mk = lab[rank].reshape(-1) == k
+        s[k], c[k] = f[mk].sum(0), int(mk.sum())
+    dist.all_reduce(s)
+    dist.all_reduce(c)
+    proto = s / c.clamp(min=1)[:, None]
+    rp, rf = O.class_prototypes(feat, lab)
+    perr = float((proto - rp).abs().max())
+    q.put((rank, err, perr, bool(torch.equal((c > 0).float(), rf))))
+    dist.destroy_process_group()
+
+
+def test_sharded_statistics_protocol_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, perr, flags_ok in res:
+        assert err < 1e-5 and perr < 1e-5 and flags_ok, (rank, err, perr)
