@@ -194,6 +194,17 @@ class Engine:
         from .dist import group_plan
         return group_plan(self.rank, self.world, self.B, rows_per_sample)
 
+    def _all_reduce(self, t):
+        """Sum over ranks, in place.  RCCL ("nccl") reduces the device tensor on the stream; with the gloo backend
+        (single-GPU rehearsal of the protocol in tests) the tensor takes a host round trip."""
+        import torch.distributed as dist
+        if dist.get_backend(self.group) == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
+
     def _finalize(self, bn: BNP, ntiles, rows_per_sample):
         _, n_a, n_b = self._groups(rows_per_sample)
         sc, sh = self.scale[bn.off:bn.off + bn.C], self.shift[bn.off:bn.off + bn.C]
@@ -202,7 +213,7 @@ class Engine:
             import torch.distributed as dist
             sums = self.sums[:4 * bn.C]
             call("diga_bn_reduce_slab", _p(self.slab), ntiles, bn.C, _p(sums), _stream())
-            dist.all_reduce(sums, group=self.group)
+            self._all_reduce(sums)
             slab, nt = sums, 1
         call("diga_bn_finalize", _p(slab), nt, bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var), _p(bn.weight),
              _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
@@ -344,8 +355,8 @@ class Engine:
              _p(self.pool_counts), _stream())
         if self.world > 1:
             import torch.distributed as dist
-            dist.all_reduce(self.pool_sums, group=self.group)
-            dist.all_reduce(self.pool_counts, group=self.group)
+            self._all_reduce(self.pool_sums)
+            self._all_reduce(self.pool_counts)
         rho = float(cfg["proto_rho"])
         call("diga_proto_update", _p(self.pool_sums), _p(self.pool_counts), Cn, FEAT_CH, _p(self.inst_proto), _p(self.inst_flag),
              _p(self.run_proto), _p(self.run_flag), _p(self.state_flag), float(np.float32(1 - rho)), float(np.float32(rho)),
