@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="N=1 only: consecutive batch-1 frames of the stream processed per step (one trunk pass with per-sample DAM "
+                         "statistics, SAM frame by frame; bit-identical to one-frame steps, tests/test_gpu_net.py)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -96,12 +99,14 @@ def main():
     from diga_amd.engine import Engine, NetWeights
     H, W = args.height, args.width
     weights = NetWeights(synth.synth_params(0), dev)
-    eng = Engine(weights, 1, H, W, bn_lambda=CFG["bn_lambda"], group=group)
-    nf = 4
+    fif = args.frames_in_flight if world == 1 else 1
+    eng = Engine(weights, fif, H, W, bn_lambda=CFG["bn_lambda"], group=group, stream=fif > 1)
+    nf = 4 if fif == 1 else 2
     frames = []
     for i in range(nf):
-        x, y = synth.synth_frame(1000 + i * world + rank, 1, H, W)
-        frames.append((torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)))
+        xy = [synth.synth_frame(1000 + (i * fif + k) * world + rank, 1, H, W) for k in range(fif)]
+        frames.append((torch.from_numpy(np.concatenate([a for a, _ in xy])).to(dev),
+                       torch.from_numpy(np.concatenate([b for _, b in xy])).to(dev)))
 
     def step_eager(i):
         x, y = frames[i % nf]
@@ -145,28 +150,29 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
-    fps = world * args.steps / dt
+    fps = world * fif * args.steps / dt
 
     res = {
         "metric": "adapted frames/sec DeepLabV2-R101 DIGA (DAM+SAM) 1024x512", "value": round(fps, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": ("BASELINE configs[1]: DIGA TTA stream (DAM+SAM, 19 classes), batch 1 per step, online prototype/BN-stat "
-                                "updates" if world == 1 else
+        "config": {"workload": ("BASELINE configs[1]: DIGA TTA stream (DAM+SAM, 19 classes), batch 1, online per-frame prototype/BN-stat "
+                                "updates" + (f"; {fif} consecutive frames in flight per step (per-sample DAM statistics, sequential SAM; "
+                                             "bit-identical to one-frame steps)" if fif > 1 else "; one frame per step") if world == 1 else
                                 f"BASELINE configs[2]: global batch {world} = 1 frame per GPU, BN sum/sumsq + prototype sums all-reduced (RCCL)"),
                    "resolution": f"{W}x{H}", "feature_grid": f"{eng.wd}x{eng.h}", "weights": "seeded synthetic init (diga_amd/synth.py)",
                    "launch": "hipGraph replay" if use_graph else "eager", "includes": "net + SAM + fusion + upsample/argmax/confusion tail",
-                   "conv_gflop_per_frame": round(eng.conv_flops / 1e9, 3)},
+                   "frames_per_step": fif, "conv_gflop_per_frame": round(eng.conv_flops / fif / 1e9, 3)},
     }
     if rank == 0 and world == 1 and not args.no_roofline:
         meta, ms = conv_profile(eng, frames, CFG)
         total_ms = float(ms.sum())
         igemm_flops = float(sum(f for _, f in meta))
         ach = igemm_flops / (total_ms * 1e-3) / 1e12
-        res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (all igemm launches of one frame)",
+        res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (all igemm launches of one step)",
                            "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                           "traffic": None, "launches_per_frame": len(meta), "avg_launch_us": round(total_ms * 1e3 / len(meta), 2),
-                           "kernel_ms_per_frame": round(total_ms, 4), "algorithmic_gflop_per_frame": round(igemm_flops / 1e9, 3)}
+                           "traffic": None, "launches_per_step": len(meta), "avg_launch_us": round(total_ms * 1e3 / len(meta), 2),
+                           "kernel_ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(igemm_flops / 1e9, 3)}
         if args.dump:
             with open(args.dump, "w") as f:
                 json.dump([dict(name=n, gflop=fl / 1e9, us=float(m) * 1e3, tflops=fl / (float(m) * 1e-3) / 1e12)

@@ -19,7 +19,7 @@ class ConvDesc(C.Structure):
                 ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
                 ("stride", C.c_int32), ("ntaps", C.c_int32),
                 ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS),
-                ("cout_pad", C.c_int32), ("split_row", C.c_int32), ("splitk", C.c_int32),
+                ("cout_pad", C.c_int32), ("splitk", C.c_int32),
                 ("out_f32", C.c_int32), ("tile", C.c_int32)]
 
 
@@ -33,17 +33,18 @@ _vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 SIGNATURES = {
     "diga_version": (_i, []),
     "diga_last_error_string": (C.c_char_p, []),
-    "diga_conv_num_mtiles": (_i, [C.POINTER(ConvDesc)]),
+    "diga_conv_stat_units": (_i, [C.POINTER(ConvDesc)]),
     "diga_conv_igemm_bf16": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
-    "diga_stem_conv7x7s2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "diga_bn_finalize": (_i, [_vp, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
-    "diga_bn_reduce_slab": (_i, [_vp, _i, _i, _vp, _vp]),
-    "diga_bn_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "diga_stem_conv7x7s2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "diga_bn_finalize": (_i, [_vp, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
+    "diga_bn_reduce_slab": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "diga_bn_finalize_sums": (_i, [_vp, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
+    "diga_bn_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "diga_bn_stats_nchw_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "diga_bn_apply_nchw_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "diga_bn_relu_maxpool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "diga_head_finish_pseudo_label": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
-    "diga_nearest_down_labels": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "diga_bn_relu_maxpool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "diga_head_finish_pseudo_label": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i64, _vp]),
+    "diga_nearest_down_labels": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _vp]),
     "diga_proto_pool_work_bytes": (_i64, [_i, _i64, _i, _i]),
     "diga_proto_pool": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "diga_proto_update": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp]),

@@ -7,41 +7,48 @@
 
 namespace {
 
-// Block = 64 channels (lanes, coalesced slab reads) x FIN_PH tile phases (waves).  Phase w sums tiles
-// w, w+FIN_PH, ... in fp64; the phases are then combined through LDS in fixed order -> deterministic.
+// Slab = [unit][2 (sum, sumsq)][C]; units are sample-major, `ups` units per sample.
+// Block = 64 channels (lanes, coalesced slab reads) x FIN_PH unit phases (waves).  Phase w sums units
+// u0+w, u0+w+FIN_PH, ... of a unit range in fp64; the phases are then combined through LDS in fixed order
+// -> deterministic, and a sample's result does not depend on which batch it is part of.
 constexpr int FIN_PH = 16;
 
-__device__ __forceinline__ void slab_phase_sums(const float* __restrict__ slab, int ntiles, int C, int c, int ph, double* s) {
-  s[0] = s[1] = s[2] = s[3] = 0;
+__device__ __forceinline__ void slab_range_sums(const float* __restrict__ slab, int u0, int u1, int C, int c, int ph, double* s) {
+  s[0] = s[1] = 0;
 #pragma unroll 4
-  for (int t = ph; t < ntiles; t += FIN_PH) {
-    const float* q = slab + (size_t)t * 4 * C + c;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) s[k] += (double)q[k * C];
+  for (int u = u0 + ph; u < u1; u += FIN_PH) {
+    const float* q = slab + (size_t)u * 2 * C + c;
+    s[0] += (double)q[0];
+    s[1] += (double)q[C];
   }
 }
 
-__global__ __launch_bounds__(64 * FIN_PH) void bn_finalize_kernel(const float* __restrict__ slab, int ntiles, int C, double n_a,
-                                                                 double n_b, const float* __restrict__ rmean,
-                                                                 const float* __restrict__ rvar, const float* __restrict__ weight,
-                                                                 const float* __restrict__ bias, float lam, float eps,
-                                                                 float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double red[FIN_PH][4][64];
+// sums of group A (units [a0,a1)) and group B (units [a1,b1)) -> s[4] valid in phase 0 of the block
+__device__ __forceinline__ void slab_group_sums(const float* __restrict__ slab, int a0, int a1, int b1, int C, int c, bool live,
+                                                double (*red)[4][64], double* s) {
   const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  double s[4];
-  if (c < C) slab_phase_sums(slab, ntiles, C, c, ph, s);
-  else s[0] = s[1] = s[2] = s[3] = 0;
+  s[0] = s[1] = s[2] = s[3] = 0;
+  if (live) {
+    slab_range_sums(slab, a0, a1, C, c, ph, s);
+    slab_range_sums(slab, a1, b1, C, c, ph, s + 2);
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) red[ph][k][lane] = s[k];
   __syncthreads();
-  if (ph != 0 || c >= C) return;
+  if (ph != 0) return;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     double v = 0;
     for (int w = 0; w < FIN_PH; ++w) v += red[w][k][lane];
     s[k] = v;
   }
+}
+
+// group sums (fp64) -> lambda-mixed scale/shift of channel c  (ttda:313-343)
+__device__ __forceinline__ void dam_affine_from_sums(const double* s, int c, double n_a, double n_b, const float* __restrict__ rmean,
+                                                     const float* __restrict__ rvar, const float* __restrict__ weight,
+                                                     const float* __restrict__ bias, float lam, float eps,
+                                                     float* __restrict__ scale, float* __restrict__ shift) {
   const double K = (double)rmean[c];
   const double ma = s[0] / n_a;
   float mean_cur = (float)(K + ma);
@@ -61,24 +68,49 @@ __global__ __launch_bounds__(64 * FIN_PH) void bn_finalize_kernel(const float* _
   shift[c] = bias[c] - mean * sc;
 }
 
-__global__ __launch_bounds__(64 * FIN_PH) void bn_reduce_slab_kernel(const float* __restrict__ slab, int ntiles, int C,
-                                                                    float* __restrict__ sums) {
+__global__ __launch_bounds__(64 * FIN_PH) void bn_finalize_kernel(const float* __restrict__ slab, int ups, int nsamples, int a_samples,
+                                                                 int per_sample, int C, double n_a, double n_b,
+                                                                 const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                                 const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                 float lam, float eps, float* __restrict__ scale,
+                                                                 float* __restrict__ shift) {
+  __shared__ double red[FIN_PH][4][64];
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  int a0, a1, b1;
+  if (per_sample) {                  // blockIdx.y = sample: its own statistics alone (a batch-1 frame of a stream)
+    a0 = blockIdx.y * ups, a1 = a0 + ups, b1 = a1;
+    scale += (size_t)blockIdx.y * C;
+    shift += (size_t)blockIdx.y * C;
+  } else {                           // half_first (ttda:313-320): group A = the first a_samples samples, B = the rest
+    a0 = 0, a1 = a_samples * ups, b1 = nsamples * ups;
+  }
+  double s[4];
+  slab_group_sums(slab, a0, a1, b1, C, c, c < C, red, s);
+  if (ph != 0 || c >= C) return;
+  dam_affine_from_sums(s, c, n_a, n_b, rmean, rvar, weight, bias, lam, eps, scale, shift);
+}
+
+__global__ void bn_finalize_sums_kernel(const double* __restrict__ sums, int C, double n_a, double n_b, const float* __restrict__ rmean,
+                                        const float* __restrict__ rvar, const float* __restrict__ weight,
+                                        const float* __restrict__ bias, float lam, float eps, float* __restrict__ scale,
+                                        float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double s[4] = {sums[c], sums[C + c], sums[2 * C + c], sums[3 * C + c]};
+  dam_affine_from_sums(s, c, n_a, n_b, rmean, rvar, weight, bias, lam, eps, scale, shift);
+}
+
+__global__ __launch_bounds__(64 * FIN_PH) void bn_reduce_slab_kernel(const float* __restrict__ slab, int ups, int nsamples,
+                                                                    int a_samples, int C, double* __restrict__ sums) {
   __shared__ double red[FIN_PH][4][64];
   const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   double s[4];
-  if (c < C) slab_phase_sums(slab, ntiles, C, c, ph, s);
-  else s[0] = s[1] = s[2] = s[3] = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) red[ph][k][lane] = s[k];
-  __syncthreads();
+  slab_group_sums(slab, 0, a_samples * ups, nsamples * ups, C, c, c < C, red, s);
   if (ph != 0 || c >= C) return;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    double v = 0;
-    for (int w = 0; w < FIN_PH; ++w) v += red[w][k][lane];
-    sums[k * C + c] = (float)v;
-  }
+  for (int k = 0; k < 4; ++k) sums[k * C + c] = s[k];
 }
 
 // rows x C elementwise.  A thread owns one 8-channel octet (16 B) and walks rows, so its 8 scale/shift
@@ -89,8 +121,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const u32x4* __restrict__
                                                        const float* __restrict__ shift, const u32x4* __restrict__ res,
                                                        const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                        u32x4* __restrict__ out, int64_t M, int C8, int relu,
-                                                       int rows_per_block) {
+                                                       int rows_per_block, int per_sample) {
   const int oct = threadIdx.x % C8, rsub = threadIdx.x / C8, rstep = 256 / C8;
+  // blockIdx.y = sample; M = rows of one sample.  per_sample: every sample has its own affine ([nsamples][C])
+  const size_t sbase = (size_t)blockIdx.y * M * C8;
+  raw += sbase;
+  out += sbase;
+  if (MODE != 0) res += sbase;
+  if (per_sample) {
+    scale += (size_t)blockIdx.y * C8 * 8;
+    shift += (size_t)blockIdx.y * C8 * 8;
+    if (MODE == 2) {
+      rscale += (size_t)blockIdx.y * C8 * 8;
+      rshift += (size_t)blockIdx.y * C8 * 8;
+    }
+  }
   float sc[8], sh[8], rsc[8], rsh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -121,7 +166,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const u32x4* __restrict__
 
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const u32x4* __restrict__ raw, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, u32x4* __restrict__ out,
-                                                              int B, int H, int W, int C8, int Ho, int Wo) {
+                                                              int B, int H, int W, int C8, int Ho, int Wo, int per_sample) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)B * Ho * Wo * C8;
   if (idx >= total) return;
@@ -130,11 +175,12 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const u32x4* __res
   const int ow = (int)(pix % Wo);
   pix /= Wo;
   const int oh = (int)(pix % Ho), n = (int)(pix / Ho);
+  const int aoff = per_sample ? n * C8 * 8 : 0;
   float sc[8], sh[8], best[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    sc[i] = scale[oct * 8 + i];
-    sh[i] = shift[oct * 8 + i];
+    sc[i] = scale[aoff + oct * 8 + i];
+    sh[i] = shift[aoff + oct * 8 + i];
     best[i] = -INFINITY;
   }
 #pragma unroll
@@ -187,7 +233,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, unsigned short
 
 // Stand-alone DAM statistics for an fp32 NCHW tensor (the SIFABatchNorm2d module used on its own):
 // one block per channel; per-thread shifted sums, 64-lane wavefront shuffle reduction, then a fixed-order
-// combine of the 4 waves through LDS.  Writes a 1-tile slab that diga_bn_finalize consumes.
+// combine of the 4 waves through LDS.  Writes [2 groups][2][C] = a slab of two one-unit samples for diga_bn_finalize.
 __global__ __launch_bounds__(256) void bn_stats_nchw_kernel(const float* __restrict__ x, int B, int C, int HW, int split_b,
                                                             const float* __restrict__ shift, float* __restrict__ slab) {
   __shared__ double red[4][4];
@@ -226,50 +272,74 @@ __global__ void bn_apply_nchw_kernel(const float* __restrict__ x, const float* _
 
 }  // namespace
 
-extern "C" int diga_bn_finalize(const float* slab, int ntiles, int C, double n_a, double n_b, const float* running_mean,
-                                const float* running_var, const float* weight, const float* bias, float lam, float eps,
-                                float* scale, float* shift, void* stream) {
+extern "C" int diga_bn_finalize(const float* slab, int units_per_sample, int nsamples, int a_samples, int per_sample, int C,
+                                double n_a, double n_b, const float* running_mean, const float* running_var,
+                                const float* weight, const float* bias, float lam, float eps, float* scale, float* shift,
+                                void* stream) {
   DIGA_CHECK_ARG(slab && running_mean && running_var && weight && bias && scale && shift, "diga_bn_finalize: NULL pointer");
-  DIGA_CHECK_ARG(ntiles > 0 && C > 0 && n_a > 0 && n_b >= 0, "diga_bn_finalize: bad sizes ntiles=%d C=%d", ntiles, C);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64 * FIN_PH), 0, (hipStream_t)stream, slab, ntiles, C, n_a, n_b,
-                     running_mean, running_var, weight, bias, lam, eps, scale, shift);
+  DIGA_CHECK_ARG(units_per_sample > 0 && nsamples > 0 && C > 0 && n_a > 0 && n_b >= 0,
+                 "diga_bn_finalize: bad sizes units_per_sample=%d nsamples=%d C=%d", units_per_sample, nsamples, C);
+  DIGA_CHECK_ARG(a_samples >= 0 && a_samples <= nsamples, "diga_bn_finalize: a_samples=%d outside [0,%d]", a_samples, nsamples);
+  DIGA_CHECK_ARG(!per_sample || n_b == 0, "diga_bn_finalize: per_sample statistics have no group B");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64), per_sample ? nsamples : 1), dim3(64 * FIN_PH), 0, (hipStream_t)stream,
+                     slab, units_per_sample, nsamples, a_samples, per_sample, C, n_a, n_b, running_mean, running_var, weight, bias,
+                     lam, eps, scale, shift);
   DIGA_CHECK_LAUNCH("diga_bn_finalize");
   return DIGA_OK;
 }
 
-extern "C" int diga_bn_reduce_slab(const float* slab, int ntiles, int C, float* sums, void* stream) {
-  DIGA_CHECK_ARG(slab && sums && ntiles > 0 && C > 0, "diga_bn_reduce_slab: bad argument");
-  hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(cdiv(C, 64)), dim3(64 * FIN_PH), 0, (hipStream_t)stream, slab, ntiles, C, sums);
+extern "C" int diga_bn_finalize_sums(const double* sums, int C, double n_a, double n_b, const float* running_mean,
+                                     const float* running_var, const float* weight, const float* bias, float lam, float eps,
+                                     float* scale, float* shift, void* stream) {
+  DIGA_CHECK_ARG(sums && running_mean && running_var && weight && bias && scale && shift, "diga_bn_finalize_sums: NULL pointer");
+  DIGA_CHECK_ARG(C > 0 && n_a > 0 && n_b >= 0, "diga_bn_finalize_sums: bad sizes C=%d", C);
+  hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, C, n_a, n_b, running_mean,
+                     running_var, weight, bias, lam, eps, scale, shift);
+  DIGA_CHECK_LAUNCH("diga_bn_finalize_sums");
+  return DIGA_OK;
+}
+
+extern "C" int diga_bn_reduce_slab(const float* slab, int units_per_sample, int nsamples, int a_samples, int C, double* sums,
+                                   void* stream) {
+  DIGA_CHECK_ARG(slab && sums && units_per_sample > 0 && nsamples > 0 && C > 0 && a_samples >= 0 && a_samples <= nsamples,
+                 "diga_bn_reduce_slab: bad argument");
+  hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(cdiv(C, 64)), dim3(64 * FIN_PH), 0, (hipStream_t)stream, slab, units_per_sample,
+                     nsamples, a_samples, C, sums);
   DIGA_CHECK_LAUNCH("diga_bn_reduce_slab");
   return DIGA_OK;
 }
 
 extern "C" int diga_bn_apply(const void* raw, const float* scale, const float* shift, const void* res,
                              const float* res_scale, const float* res_shift, void* out, int64_t M, int C, int relu,
-                             void* stream) {
+                             int nsamples_affine, void* stream) {
   DIGA_CHECK_ARG(raw && scale && shift && out, "diga_bn_apply: NULL pointer");
   DIGA_CHECK_ARG(M > 0 && C >= 64 && C <= 2048 && (C & (C - 1)) == 0, "diga_bn_apply: C=%d must be a power of two in [64,2048]", C);
   DIGA_CHECK_ARG((res_scale == nullptr) == (res_shift == nullptr), "diga_bn_apply: res_scale/res_shift go together");
   DIGA_CHECK_ARG(res != nullptr || res_scale == nullptr, "diga_bn_apply: residual affine without residual");
+  DIGA_CHECK_ARG(nsamples_affine >= 0 && (nsamples_affine == 0 || M % nsamples_affine == 0),
+                 "diga_bn_apply: M=%lld is not a whole number of %d samples", (long long)M, nsamples_affine);
+  const int ns = nsamples_affine > 0 ? nsamples_affine : 1;
+  const int64_t Ms = M / ns;                     // rows handled per grid.y slice
   const int C8 = C / 8, rstep = 256 / C8;
-  int rpb = cdiv(M, 2048);
+  int rpb = cdiv(Ms, cdiv(2048, ns));
   rpb = cdiv(rpb, rstep) * rstep;
-  const dim3 grid(cdiv(M, rpb)), block(256);
+  const dim3 grid(cdiv(Ms, rpb), ns), block(256);
   hipStream_t st = (hipStream_t)stream;
   const u32x4* r = (const u32x4*)raw;
   const u32x4* q = (const u32x4*)res;
+  const int ps = nsamples_affine > 0;
   if (!res)
-    hipLaunchKernelGGL(bn_apply_kernel<0>, grid, block, 0, st, r, scale, shift, q, res_scale, res_shift, (u32x4*)out, M, C8, relu, rpb);
+    hipLaunchKernelGGL(bn_apply_kernel<0>, grid, block, 0, st, r, scale, shift, q, res_scale, res_shift, (u32x4*)out, Ms, C8, relu, rpb, ps);
   else if (!res_scale)
-    hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, st, r, scale, shift, q, res_scale, res_shift, (u32x4*)out, M, C8, relu, rpb);
+    hipLaunchKernelGGL(bn_apply_kernel<1>, grid, block, 0, st, r, scale, shift, q, res_scale, res_shift, (u32x4*)out, Ms, C8, relu, rpb, ps);
   else
-    hipLaunchKernelGGL(bn_apply_kernel<2>, grid, block, 0, st, r, scale, shift, q, res_scale, res_shift, (u32x4*)out, M, C8, relu, rpb);
+    hipLaunchKernelGGL(bn_apply_kernel<2>, grid, block, 0, st, r, scale, shift, q, res_scale, res_shift, (u32x4*)out, Ms, C8, relu, rpb, ps);
   DIGA_CHECK_LAUNCH("diga_bn_apply");
   return DIGA_OK;
 }
 
 extern "C" int diga_bn_relu_maxpool(const void* raw, const float* scale, const float* shift, void* out, int B, int H, int W,
-                                    int C, int Ho, int Wo, void* stream) {
+                                    int C, int Ho, int Wo, int per_sample, void* stream) {
   DIGA_CHECK_ARG(raw && scale && shift && out, "diga_bn_relu_maxpool: NULL pointer");
   DIGA_CHECK_ARG(B > 0 && H > 1 && W > 1 && C % 8 == 0, "diga_bn_relu_maxpool: bad dims");
   // PyTorch ceil_mode rule for k=3, s=2, p=1: o = ceil((H-1)/2)+1, minus one if the last window starts beyond the input
@@ -281,7 +351,7 @@ extern "C" int diga_bn_relu_maxpool(const void* raw, const float* scale, const f
   DIGA_CHECK_ARG(Ho == osz(H) && Wo == osz(W), "diga_bn_relu_maxpool: output %dx%d does not match ceil-mode pooling of %dx%d", Ho, Wo, H, W);
   const int64_t total = (int64_t)B * Ho * Wo * (C / 8);
   hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)raw, scale,
-                     shift, (u32x4*)out, B, H, W, C / 8, Ho, Wo);
+                     shift, (u32x4*)out, B, H, W, C / 8, Ho, Wo, per_sample);
   DIGA_CHECK_LAUNCH("diga_bn_relu_maxpool");
   return DIGA_OK;
 }

@@ -32,7 +32,7 @@ struct ConvKParams {
   float* slab;
   const float* shift;
   int H, W, Cin, Ho, Wo, Cout, stride, ntaps;
-  int M, K, cout_pad, split_row, nk_total, nk_per_split, mtiles, ntiles_n;
+  int M, K, cout_pad, hw, tiles_per_sample, units_per_sample, nk_total, nk_per_split, mtiles, ntiles_n;
   unsigned in_bytes, wgt_bytes;
   int dydx[DIGA_MAX_TAPS];   // (dy << 16) | (dx & 0xffff): 32-bit so that the uniform per-tap lookup is a scalar load
 };
@@ -70,7 +70,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int mtile = bid / p.ntiles_n, ntile = bid - mtile * p.ntiles_n;
-  const int m0 = mtile * BM, n0 = ntile * BN;
+  // M tiles never straddle samples: tile -> (sample, tile within the sample).  A sample's rows are tiled from
+  // its own row 0, so its results (and its 32-row statistics units) do not depend on the batch it rides in.
+  const int n_img = mtile / p.tiles_per_sample;
+  const int r0 = (mtile - n_img * p.tiles_per_sample) * BM;     // first row of the tile inside the sample
+  const int m_base = n_img * p.hw;                              // global output row of the sample's row 0
+  const int n0 = ntile * BN;
   const int ks_begin = blockIdx.y * p.nk_per_split;
   const int ks_end = min(ks_begin + p.nk_per_split, p.nk_total);
   const int nt = ks_end - ks_begin;
@@ -87,14 +92,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   int pixoff[A_CH], ih0[A_CH], iw0[A_CH];
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
-    const int m = m0 + lrow + 32 * i;
-    if (m < p.M) {
-      const int hw = p.Ho * p.Wo;
-      const int n = m / hw, rem = m - n * hw;
+    const int rem = r0 + lrow + 32 * i;
+    if (rem < p.hw) {
       const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
       ih0[i] = oh * p.stride;
       iw0[i] = ow * p.stride;
-      pixoff[i] = ((n * p.H + ih0[i]) * p.W + iw0[i]) * p.Cin + cch * 8;
+      pixoff[i] = ((n_img * p.H + ih0[i]) * p.W + iw0[i]) * p.Cin + cch * 8;
     } else {
       ih0[i] = -100000;  // every tap lands outside the image -> zeros
       iw0[i] = 0;
@@ -175,66 +178,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   // ------------------------------------------------------------------ epilogue
   // accumulator element r of tile (a,b): row = wm*WTM + a*32 + (r&3) + 8*(r>>2) + 4*hh, col = wn*WTN + b*32 + l31
   if constexpr (STATS) {
-    float* red = reinterpret_cast<float*>(smem);     // [WM][2 grp][2 stat][BN]
-    const bool one_group = (m0 + BM <= p.split_row) || (m0 >= p.split_row && m0 + BM <= p.M);
-    const int g_fast = m0 >= p.split_row ? 1 : 0;
+    // One statistics unit = the 32 rows of one MFMA tile row-block: lane (l31, hh) holds 16 of the 32 rows of
+    // column l31, the other half-wave holds the rest -> 16 adds + one cross-half shuffle, no LDS, and the unit's
+    // value does not depend on the tile shape.  Units that lie entirely in the sample's padding are skipped.
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
-      const int c = n0 + wn * WTN + b * 32 + l31;
-      const float kshift = c < p.Cout ? p.shift[c] : 0.f;
-      float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-      if (one_group) {
-        float t1 = 0.f, t2 = 0.f;
+    for (int a = 0; a < MT; ++a) {
+      const int ubase = r0 + wm * WTM + a * 32;        // first row (inside the sample) of this unit: wave-uniform
+      if (ubase < p.hw) {
+        const bool full = ubase + 32 <= p.hw;
+        const size_t urow = ((size_t)n_img * p.units_per_sample + (ubase >> 5)) * 2;
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+        for (int b = 0; b < NT; ++b) {
+          const int c = n0 + wn * WTN + b * 32 + l31;
+          const float kshift = c < p.Cout ? p.shift[c] : 0.f;
+          float t1 = 0.f, t2 = 0.f;
+          if (full) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float d = acc[a][b][r] - kshift;
-            t1 += d;
-            t2 = fmaf(d, d, t2);
-          }
-        s1[g_fast] = t1;
-        s2[g_fast] = t2;
-      } else {
+            for (int r = 0; r < 16; ++r) {
+              const float d = acc[a][b][r] - kshift;
+              t1 += d;
+              t2 = fmaf(d, d, t2);
+            }
+          } else {
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float d = acc[a][b][r] - kshift;
-            if (m < p.split_row) {
-              s1[0] += d;
-              s2[0] = fmaf(d, d, s2[0]);
-            } else if (m < p.M) {
-              s1[1] += d;
-              s2[1] = fmaf(d, d, s2[1]);
+            for (int r = 0; r < 16; ++r) {
+              const float d = acc[a][b][r] - kshift;
+              if (ubase + (r & 3) + 8 * (r >> 2) + 4 * hh < p.hw) {
+                t1 += d;
+                t2 = fmaf(d, d, t2);
+              }
             }
           }
-      }
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        s1[g] += __shfl_xor(s1[g], 32);
-        s2[g] += __shfl_xor(s2[g], 32);
-      }
-      if (hh == 0) {
-        const int col = wn * WTN + b * 32 + l31;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          red[((wm * 2 + g) * 2 + 0) * BN + col] = s1[g];
-          red[((wm * 2 + g) * 2 + 1) * BN + col] = s2[g];
+          t1 += __shfl_xor(t1, 32);
+          t2 += __shfl_xor(t2, 32);
+          if (c < p.Cout) p.slab[(urow + hh) * p.Cout + c] = hh ? t2 : t1;
         }
       }
     }
-    __syncthreads();
-    for (int e = tid; e < 4 * BN; e += 256) {
-      const int gs = e / BN, col = e - gs * BN;       // gs = g*2 + stat
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) v += red[(w * 4 + gs) * BN + col];
-      const int c = n0 + col;
-      if (c < p.Cout) p.slab[((size_t)mtile * 4 + gs) * p.Cout + c] = v;
-    }
-    __syncthreads();
   }
 
   if constexpr (OUT_F32) {
@@ -246,8 +226,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
         const int c = n0 + wn * WTN + b * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (m < p.M) out[(size_t)m * p.cout_pad + c] = acc[a][b][r];
+          const int rem = r0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (rem < p.hw) out[(size_t)(m_base + rem) * p.cout_pad + c] = acc[a][b][r];
         }
       }
   } else {
@@ -270,9 +250,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     for (int i = 0; i < BM * CPR / 256; ++i) {
       const int id = tid + 256 * i;
       const int row = id / CPR, cc = id - row * CPR;
-      const int m = m0 + row, c = n0 + cc * 8;
-      if (m < p.M && c < p.Cout)
-        *reinterpret_cast<u32x4*>(out + (size_t)m * p.Cout + c) = *reinterpret_cast<const u32x4*>(sC + row * BN + cc * 8);
+      const int rem = r0 + row, c = n0 + cc * 8;
+      if (rem < p.hw && c < p.Cout)
+        *reinterpret_cast<u32x4*>(out + (size_t)(m_base + rem) * p.Cout + c) = *reinterpret_cast<const u32x4*>(sC + row * BN + cc * 8);
     }
   }
 }
@@ -307,7 +287,7 @@ int auto_tile(const diga_conv_desc* d) {
 template <int BM, int BN, int WM, int WN, int S>
 int launch_cfg(const ConvKParams& p, int splitk, bool out_f32, bool stats, hipStream_t st) {
   constexpr int main_bytes = S * (BM + BN) * 128;
-  constexpr int epi_bytes = WM * 4 * BN * 4 > BM * BN * 2 ? WM * 4 * BN * 4 : BM * BN * 2;
+  constexpr int epi_bytes = BM * BN * 2;
   constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   dim3 grid(p.mtiles * p.ntiles_n, splitk), block(256);
   static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
@@ -346,17 +326,14 @@ int validate(const diga_conv_desc* d, const char* who) {
   DIGA_CHECK_ARG(in_bytes < 0x7ffffff0ll && w_bytes < 0x7ffffff0ll, "%s: tensor exceeds the 2 GiB buffer range", who);
   const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
   DIGA_CHECK_ARG(M * d->cout_pad < 0x7fffffffll, "%s: output too large", who);
-  DIGA_CHECK_ARG(d->split_row >= 0 && d->split_row <= M, "%s: split_row out of range", who);
   return DIGA_OK;
 }
 
 }  // namespace
 
-extern "C" int diga_conv_num_mtiles(const diga_conv_desc* d) {
-  if (validate(d, "diga_conv_num_mtiles") != DIGA_OK) return DIGA_EINVAL;
-  const TileCfg* t = find_tile(d->tile ? d->tile : auto_tile(d));
-  DIGA_CHECK_ARG(t != nullptr, "diga_conv_num_mtiles: unknown tile id %d", d->tile);
-  return cdiv((int64_t)d->B * d->Ho * d->Wo, t->BM);
+extern "C" int diga_conv_stat_units(const diga_conv_desc* d) {
+  if (validate(d, "diga_conv_stat_units") != DIGA_OK) return DIGA_EINVAL;
+  return d->B * cdiv(d->Ho * d->Wo, 32);
 }
 
 extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, const void* wgt, void* out,
@@ -378,10 +355,12 @@ extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, con
   p.M = d->B * d->Ho * d->Wo;
   p.K = d->ntaps * d->Cin;
   p.cout_pad = d->cout_pad;
-  p.split_row = d->split_row;
+  p.hw = d->Ho * d->Wo;
+  p.tiles_per_sample = cdiv(p.hw, t->BM);
+  p.units_per_sample = cdiv(p.hw, 32);
   p.nk_total = p.K / 64;
   p.nk_per_split = cdiv(p.nk_total, d->splitk);
-  p.mtiles = cdiv(p.M, t->BM);
+  p.mtiles = d->B * p.tiles_per_sample;
   p.ntiles_n = d->cout_pad / t->BN;
   p.in_bytes = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * 2);
   p.wgt_bytes = (unsigned)((int64_t)d->cout_pad * p.K * 2);

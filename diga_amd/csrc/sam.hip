@@ -12,7 +12,7 @@ namespace {
 __global__ __launch_bounds__(256) void head_finish_pl_kernel(const float* __restrict__ partials, int splitk, int cpad,
                                                              const float* __restrict__ bias, const float* __restrict__ logits_in,
                                                              float* __restrict__ logits_out, int32_t* __restrict__ labels,
-                                                             int64_t P, int C, int hw, float thr) {
+                                                             int64_t P, int C, int hw, float thr, int64_t lstride) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
   const int64_t b = p / hw, pix = p - b * hw;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void head_finish_pl_kernel(const float* __rest
   float sum = 0.f;
   for (int c = 0; c < C; ++c) sum += expf(l[c] - mx);
   const float pmax = 1.0f / sum;        // exp(0)/sum
-  labels[p] = (pmax < thr) ? 255 : am;  // NaN < thr is false -> keeps argmax, as the reference
+  labels[b * lstride + pix] = (pmax < thr) ? 255 : am;  // NaN < thr is false -> keeps argmax, as the reference
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -55,11 +55,12 @@ __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
 }
 
 template <typename T>
-__global__ void nearest_down_kernel(const T* __restrict__ y, int32_t* __restrict__ out, int B, int H, int W, int h, int w) {
+__global__ void nearest_down_kernel(const T* __restrict__ y, int32_t* __restrict__ out, int B, int H, int W, int h, int w,
+                                    int64_t ostride) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)B * h * w) return;
   const int ox = (int)(i % w), oy = (int)((i / w) % h), b = (int)(i / ((int64_t)w * h));
-  out[i] = (int32_t)y[((size_t)b * H + nearest_src(oy, H, h)) * W + nearest_src(ox, W, w)];
+  out[b * ostride + (int64_t)oy * w + ox] = (int32_t)y[((size_t)b * H + nearest_src(oy, H, h)) * W + nearest_src(ox, W, w)];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -294,27 +295,30 @@ __global__ __launch_bounds__(256) void proto_classify_fuse_kernel(const unsigned
 
 extern "C" int diga_head_finish_pseudo_label(const float* partials, int splitk, int cpad, const float* bias_sum,
                                              const float* logits_in, float* logits_out, int32_t* labels, int B, int C, int hw,
-                                             float threshold, void* stream) {
+                                             float threshold, int64_t label_sample_stride, void* stream) {
   DIGA_CHECK_ARG((partials != nullptr) != (logits_in != nullptr), "diga_head_finish_pseudo_label: give partials or logits_in");
   DIGA_CHECK_ARG(labels && B > 0 && hw > 0 && C > 0 && C <= DIGA_NUM_CLASSES_MAX, "diga_head_finish_pseudo_label: bad argument");
   DIGA_CHECK_ARG(!partials || (bias_sum && splitk >= 1 && cpad >= C), "diga_head_finish_pseudo_label: bad partials description");
+  DIGA_CHECK_ARG(label_sample_stride == 0 || label_sample_stride >= hw, "diga_head_finish_pseudo_label: label stride < hw");
   const int64_t P = (int64_t)B * hw;
   hipLaunchKernelGGL(head_finish_pl_kernel, dim3(cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, partials, splitk, cpad,
-                     bias_sum, logits_in, logits_out, labels, P, C, hw, threshold);
+                     bias_sum, logits_in, logits_out, labels, P, C, hw, threshold, label_sample_stride ? label_sample_stride : (int64_t)hw);
   DIGA_CHECK_LAUNCH("diga_head_finish_pseudo_label");
   return DIGA_OK;
 }
 
 extern "C" int diga_nearest_down_labels(const void* y, int y_is_i64, int32_t* out, int B, int H, int W, int h, int w,
-                                        void* stream) {
+                                        int64_t out_sample_stride, void* stream) {
   DIGA_CHECK_ARG(y && out && B > 0 && H > 0 && W > 0 && h > 0 && w > 0, "diga_nearest_down_labels: bad argument");
+  DIGA_CHECK_ARG(out_sample_stride == 0 || out_sample_stride >= (int64_t)h * w, "diga_nearest_down_labels: output stride < h*w");
+  const int64_t os = out_sample_stride ? out_sample_stride : (int64_t)h * w;
   const int64_t n = (int64_t)B * h * w;
   if (y_is_i64)
     hipLaunchKernelGGL(nearest_down_kernel<int64_t>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const int64_t*)y, out,
-                       B, H, W, h, w);
+                       B, H, W, h, w, os);
   else
     hipLaunchKernelGGL(nearest_down_kernel<int32_t>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const int32_t*)y, out,
-                       B, H, W, h, w);
+                       B, H, W, h, w, os);
   DIGA_CHECK_LAUNCH("diga_nearest_down_labels");
   return DIGA_OK;
 }

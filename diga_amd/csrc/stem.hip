@@ -1,6 +1,6 @@
 // Stem convolution (adaptseg.py:133,178): 7x7, stride 2, pad 3, 3 -> 64 channels.
 // Input is the caller's fp32 NCHW frame (BGR, mean-subtracted), output is the raw bf16 NHWC map that
-// bn1+ReLU+maxpool consumes, plus the DAM statistics slab (same format as the igemm epilogue).
+// bn1+ReLU+maxpool consumes, plus the DAM statistics slab (one unit per block, sample-major: [unit][2][64]).
 //
 // Cin = 3 makes this a 147-deep dot product per output: too thin for the generic 64-channel gather,
 // and only 0.3 % of the frame's FLOPs, so it runs on the fp32 VALU from LDS: a block owns a strip of
@@ -16,7 +16,7 @@ constexpr int PW = 134;        // patch row pitch (133 used)
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                    unsigned short* __restrict__ out, float* __restrict__ slab,
                                                    const float* __restrict__ shift, int H, int W, int Ho, int Wo,
-                                                   int tiles_w, int tiles_h, int split_row) {
+                                                   int tiles_w, int tiles_h) {
   __shared__ __attribute__((aligned(16))) float sw[147 * 64];   // [k][cout]
   __shared__ float sp[3 * 7 * PW];
   __shared__ float sred[4][2][16];
@@ -104,28 +104,25 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     }
   }
   __syncthreads();
-  if (tid < 256) {
-    // slab tile = this block: [tile][g][stat][64]
-    const int gs = tid >> 6, c = tid & 63;               // gs = g*2 + stat
-    const int g = ((size_t)n * Ho * Wo >= (size_t)split_row) ? 1 : 0;
-    const float v = (gs >> 1) == g ? sred[c >> 4][gs & 1][c & 15] : 0.f;
-    slab[((size_t)blockIdx.x * 4 + gs) * 64 + c] = v;
+  if (tid < 128) {
+    // statistics unit = this block: slab[unit][stat][64]; units are numbered sample-major
+    const int stat = tid >> 6, c = tid & 63;
+    slab[((size_t)blockIdx.x * 2 + stat) * 64 + c] = sred[c >> 4][stat][c & 15];
   }
 }
 
 }  // namespace
 
 extern "C" int diga_stem_conv7x7s2(const float* x, const float* wgt, void* out, float* stat_slab, const float* stat_shift,
-                                   int B, int H, int W, int split_row, void* stream) {
+                                   int B, int H, int W, void* stream) {
   DIGA_CHECK_ARG(B > 0 && H >= 7 && W >= 7, "diga_stem_conv7x7s2: bad dims %dx%dx%d", B, H, W);
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   const int tiles_w = cdiv(Wo, 64), tiles_h = cdiv(Ho, ROWS);
   const int ntiles = B * tiles_h * tiles_w;
   if (x == nullptr) return ntiles;
   DIGA_CHECK_ARG(wgt && out && stat_slab && stat_shift, "diga_stem_conv7x7s2: NULL pointer");
-  DIGA_CHECK_ARG(split_row % (Ho * Wo) == 0 && split_row >= 0, "diga_stem_conv7x7s2: split_row must be a whole number of frames");
   hipLaunchKernelGGL(stem_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, x, wgt, (unsigned short*)out, stat_slab,
-                     stat_shift, H, W, Ho, Wo, tiles_w, tiles_h, split_row);
+                     stat_shift, H, W, Ho, Wo, tiles_w, tiles_h);
   DIGA_CHECK_LAUNCH("diga_stem_conv7x7s2");
   return DIGA_OK;
 }

@@ -126,8 +126,16 @@ class Engine:
     """Static plan + buffers for one input shape (B, H, W) on the current device."""
 
     def __init__(self, weights: NetWeights, B: int, H: int, W: int, bn_lambda: float = 0.8, group=None,
-                 head_splitk: int = 4, confidence_threshold: float = 0.9):
+                 head_splitk: int = 4, confidence_threshold: float = 0.9, stream: bool = False, conv_tile: int = 0):
+        """stream=False: x is ONE batch of B samples -> the reference's batch semantics (half_first DAM statistics over
+        the batch, prototypes pooled over the batch).  stream=True: x holds B CONSECUTIVE batch-1 frames of a stream
+        ("frames in flight"): the trunk runs once over all of them with per-sample DAM statistics (DAM carries no
+        state between frames), SAM/fusion then run frame by frame in order, so every frame's result is bit-identical
+        to B separate batch-1 steps (tests/test_gpu_net.py::test_stream_mode_is_bit_identical_to_batch1_steps)."""
         _lib.load()
+        self.stream = bool(stream)
+        self.conv_tile = conv_tile
+        assert not (stream and group is not None), "stream mode pipelines frames on one GPU; shard batches instead"
         self.w = weights
         self.dev = weights.device
         self.B, self.H, self.W = B, H, W
@@ -161,17 +169,24 @@ class Engine:
         mid = max(n2 * 64, n2 * 128, n3 * 512)    # conv1 / conv2 outputs (layer2.0.conv1 is already strided)
         self.raw1, self.act1, self.raw2, self.act2 = buf(mid, bf), buf(mid, bf), buf(mid, bf), buf(mid, bf)
         self.raw3, self.rawd = buf(big, bf), buf(big, bf)
-        self.scale = buf(weights.bn_channels, f32)
-        self.shift = buf(weights.bn_channels, f32)
-        # statistics slab shared by all layers (each is consumed by its finalize before the next conv runs)
-        self.stem_tiles = call("diga_stem_conv7x7s2", None, None, None, None, None, B, H, W, 0, None)
-        self.slab = buf(max(self.stem_tiles * 4 * 64, (n2 // 64 + 2) * 4 * 256, (n3 // 64 + 2) * 4 * 2048), f32)
-        self.sums = buf(4 * 2048, f32)
+        self.na = B if self.stream else 1          # affines per BN layer: one per sample in stream mode
+        self.scale = buf(weights.bn_channels * self.na, f32)
+        self.shift = buf(weights.bn_channels * self.na, f32)
+        # statistics slab shared by all layers (each is consumed by its finalize before the next conv runs):
+        # [unit][2][C], a unit = 32 output rows of one sample (igemm) or one stem block
+        self.stem_units = call("diga_stem_conv7x7s2", None, None, None, None, None, B, H, W, None)
+
+        def units(rows):
+            return B * ((rows + 31) // 32)
+        self.slab = buf(max(self.stem_units * 2 * 64, units(self.h2 * self.w2) * 2 * 256, units(self.h3 * self.w3) * 2 * 2048), f32)
+        self.sums = buf(4 * 2048, torch.float64)
         # head / SAM
         self.head_part = buf(head_splitk * self.P * weights.head_cpad, f32)
         self.logits = torch.empty(B, self.C, self.h, self.wd, dtype=f32, device=dev)
-        self.labels = buf(2 * self.P, i32)                       # [pseudo | ground truth]
-        self.pool_work = torch.empty(int(_lib.load().diga_proto_pool_work_bytes(2, self.P, self.C, FEAT_CH)),
+        # labels: batch mode [2][P] = [pseudo | ground truth] over the batch; stream mode [B][2][hw] (per frame)
+        self.labels = buf(2 * self.P, i32)
+        self.Ps = self.hw if self.stream else self.P             # pixels one SAM pass pools over
+        self.pool_work = torch.empty(int(_lib.load().diga_proto_pool_work_bytes(2, self.Ps, self.C, FEAT_CH)),
                                      dtype=torch.uint8, device=dev)
         self.pool_sums = torch.zeros(2 * self.C * FEAT_CH, dtype=f32, device=dev)
         self.pool_counts = torch.zeros(2 * self.C, dtype=i32, device=dev)
@@ -205,19 +220,33 @@ class Engine:
         else:
             dist.all_reduce(t, group=self.group)
 
-    def _finalize(self, bn: BNP, ntiles, rows_per_sample):
-        _, n_a, n_b = self._groups(rows_per_sample)
-        sc, sh = self.scale[bn.off:bn.off + bn.C], self.shift[bn.off:bn.off + bn.C]
-        slab, nt = self.slab, ntiles
+    def _affine(self, bn: BNP):
+        n = bn.C * self.na
+        return self.scale[bn.off * self.na:bn.off * self.na + n], self.shift[bn.off * self.na:bn.off * self.na + n]
+
+    def _finalize(self, bn: BNP, ups, rows_per_sample):
+        """slab (this rank's B samples x ups units) -> scale/shift of one BN layer."""
+        sc, sh = self._affine(bn)
+        if self.stream:
+            call("diga_bn_finalize", _p(self.slab), ups, self.B, self.B, 1, bn.C, float(rows_per_sample), 0.0,
+                 _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
+            return sc, sh
+        split, n_a, n_b = self._groups(rows_per_sample)
+        a_samples = split // rows_per_sample
         if self.world > 1:
-            import torch.distributed as dist
             sums = self.sums[:4 * bn.C]
-            call("diga_bn_reduce_slab", _p(self.slab), ntiles, bn.C, _p(sums), _stream())
+            call("diga_bn_reduce_slab", _p(self.slab), ups, self.B, a_samples, bn.C, _p(sums), _stream())
             self._all_reduce(sums)
-            slab, nt = sums, 1
-        call("diga_bn_finalize", _p(slab), nt, bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var), _p(bn.weight),
-             _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
+            call("diga_bn_finalize_sums", _p(sums), bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var), _p(bn.weight),
+                 _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
+            return sc, sh
+        call("diga_bn_finalize", _p(self.slab), ups, self.B, a_samples, 0, bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var),
+             _p(bn.weight), _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
         return sc, sh
+
+    def _apply(self, raw, sc, sh, res, rsc, rsh, out, M, Cc):
+        call("diga_bn_apply", _p(raw), _p(sc), _p(sh), _p(res), _p(rsc), _p(rsh), _p(out), M, Cc, 1,
+             self.B if self.stream else 0, _stream())
 
     def _conv(self, name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn: BNP | None):
         d = ConvDesc()
@@ -230,16 +259,14 @@ class Engine:
         else:
             d.ntaps = 1
         d.cout_pad = Cout
-        d.split_row = self._groups(Ho * Wo)[0]
-        d.splitk, d.out_f32, d.tile = 1, 0, 0
-        nt = call("diga_conv_num_mtiles", C.byref(d))
+        d.splitk, d.out_f32, d.tile = 1, 0, self.conv_tile
         flops = 2 * self.B * Ho * Wo * Cout * Cin * d.ntaps
         ev = self._ev_start()
         call("diga_conv_igemm_bf16", C.byref(d), _p(x), _p(self.w.conv[name]), _p(out), _p(self.slab), _p(bn.running_mean),
              _stream())
         self._ev_end(ev, name, flops)
         self.conv_flops += flops
-        return nt
+        return (Ho * Wo + 31) // 32          # statistics units per sample
 
     def _ev_start(self):
         if self.conv_events is None:
@@ -267,15 +294,13 @@ class Engine:
         w, B = self.w, self.B
         self.conv_flops = 2 * B * self.h1 * self.w1 * 64 * 147
         bn = w.bn["bn1"]
-        split, _, _ = self._groups(self.h1 * self.w1)
         call("diga_stem_conv7x7s2", _p(x), _p(w.stem_w), _p(self.stem_raw), _p(self.slab), _p(bn.running_mean), B, self.H,
-             self.W, split, _stream())
-        ntiles = self.stem_tiles
+             self.W, _stream())
         self._tap("conv1", self.stem_raw, (B, self.h1, self.w1, 64))
-        sc, sh = self._finalize(bn, ntiles, self.h1 * self.w1)
+        sc, sh = self._finalize(bn, self.stem_units // B, self.h1 * self.w1)
         cur, nxt = self.xa, self.xb
         call("diga_bn_relu_maxpool", _p(self.stem_raw), _p(sc), _p(sh), _p(cur), B, self.h1, self.w1, 64, self.h2, self.w2,
-             _stream())
+             int(self.stream), _stream())
         self._tap("maxpool", cur, (B, self.h2, self.w2, 64))
         Hc, Wc, Cc = self.h2, self.w2, 64
         for li, (nb, pl, st, dil) in enumerate(zip(LAYERS, PLANES, STRIDES, DILATIONS), start=1):
@@ -290,14 +315,14 @@ class Engine:
                 nt = self._conv(pre + ".conv1", cur, self.raw1, Hc, Wc, Cc, Ho, Wo, pl, s, 1, False, bn1)
                 self._tap(pre + ".conv1", self.raw1, (B, Ho, Wo, pl))
                 sc, sh = self._finalize(bn1, nt, rows)
-                call("diga_bn_apply", _p(self.raw1), _p(sc), _p(sh), None, None, None, _p(self.act1), M, pl, 1, _stream())
+                self._apply(self.raw1, sc, sh, None, None, None, self.act1, M, pl)
                 self._tap(pre + ".act1", self.act1, (B, Ho, Wo, pl))
                 # conv2 (3x3 dilated, pad = dilation) -> bn2 -> relu
                 bn2 = w.bn[pre + ".bn2"]
                 nt = self._conv(pre + ".conv2", self.act1, self.raw2, Ho, Wo, pl, Ho, Wo, pl, 1, dil, True, bn2)
                 self._tap(pre + ".conv2", self.raw2, (B, Ho, Wo, pl))
                 sc, sh = self._finalize(bn2, nt, rows)
-                call("diga_bn_apply", _p(self.raw2), _p(sc), _p(sh), None, None, None, _p(self.act2), M, pl, 1, _stream())
+                self._apply(self.raw2, sc, sh, None, None, None, self.act2, M, pl)
                 self._tap(pre + ".act2", self.act2, (B, Ho, Wo, pl))
                 # conv3 (1x1) -> bn3
                 bn3 = w.bn[pre + ".bn3"]
@@ -309,22 +334,21 @@ class Engine:
                     nt = self._conv(pre + ".downsample.0", cur, self.rawd, Hc, Wc, Cc, Ho, Wo, pl * 4, s, 1, False, bnd)
                     self._tap(pre + ".downsample.0", self.rawd, (B, Ho, Wo, pl * 4))
                     scd, shd = self._finalize(bnd, nt, rows)
-                    call("diga_bn_apply", _p(self.raw3), _p(sc3), _p(sh3), _p(self.rawd), _p(scd), _p(shd), _p(nxt), M, pl * 4, 1,
-                         _stream())
+                    self._apply(self.raw3, sc3, sh3, self.rawd, scd, shd, nxt, M, pl * 4)
                 else:
-                    call("diga_bn_apply", _p(self.raw3), _p(sc3), _p(sh3), _p(cur), None, None, _p(nxt), M, pl * 4, 1, _stream())
+                    self._apply(self.raw3, sc3, sh3, cur, None, None, nxt, M, pl * 4)
                 cur, nxt = nxt, cur
                 Hc, Wc, Cc = Ho, Wo, pl * 4
                 self._tap(pre, cur, (B, Ho, Wo, Cc))
             if li == 3 and want_aux:
                 self.aux_logits = torch.empty_like(self.logits)
-                self._head(cur[:self.P * 1024], 1024, self.w.aux_w, self.w.aux_bias, self.aux_logits, self.labels[self.P:])
+                self._head(cur[:self.P * 1024], 1024, self.w.aux_w, self.w.aux_bias, self.aux_logits, self.labels[self.P:], 0)
         assert (Hc, Wc, Cc) == (self.h, self.wd, FEAT_CH)
         self.feat = cur[:self.P * FEAT_CH]
-        self._head(self.feat, FEAT_CH, self.w.head_w, self.w.head_bias, self.logits, self.labels)
+        self._head(self.feat, FEAT_CH, self.w.head_w, self.w.head_bias, self.logits, self.labels, 2 * self.hw if self.stream else 0)
         return self.feat, self.logits
 
-    def _head(self, feat, cin, hw, hbias, logits, labels):
+    def _head(self, feat, cin, hw, hbias, logits, labels, lstride):
         d = ConvDesc()
         d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = self.B, self.h, self.wd, cin, self.h, self.wd, self.C
         d.stride, d.ntaps = 1, 18
@@ -332,7 +356,6 @@ class Engine:
             for t in range(9):
                 d.dy[br * 9 + t], d.dx[br * 9 + t] = (t // 3 - 1) * dil, (t % 3 - 1) * dil
         d.cout_pad = self.w.head_cpad
-        d.split_row = self.P
         d.splitk, d.out_f32, d.tile = self.head_splitk, 1, 0
         ev = self._ev_start()
         call("diga_conv_igemm_bf16", C.byref(d), _p(feat), _p(hw), _p(self.head_part), None, None, _stream())
@@ -340,7 +363,7 @@ class Engine:
         self.conv_flops += 2 * self.P * self.C * cin * 18
         # split-K partials + bias -> logits (NCHW fp32) and the confidence-thresholded pseudo labels (ttda:1662-1676)
         call("diga_head_finish_pseudo_label", _p(self.head_part), self.head_splitk, self.w.head_cpad, _p(hbias), None,
-             _p(logits), _p(labels), self.B, self.C, self.hw, self.threshold, _stream())
+             _p(logits), _p(labels), self.B, self.C, self.hw, self.threshold, lstride, _stream())
 
     # ------------------------------------------------------------------ SAM + fusion
     def sam_fuse(self, y: torch.Tensor, cfg):
@@ -349,22 +372,29 @@ class Engine:
         B, Cn = self.B, self.C
         assert y.shape[0] == B and y.dtype in (torch.int64, torch.int32) and y.is_contiguous()
         assert float(np.float32(cfg["confidence_threshold"])) == self.threshold
-        call("diga_nearest_down_labels", _p(y), int(y.dtype == torch.int64), _p(self.labels[self.P:]), B, y.shape[1], y.shape[2],
-             self.h, self.wd, _stream())
-        call("diga_proto_pool", _p(self.feat), _p(self.labels), 2, self.P, Cn, FEAT_CH, _p(self.pool_work), _p(self.pool_sums),
-             _p(self.pool_counts), _stream())
-        if self.world > 1:
-            import torch.distributed as dist
-            self._all_reduce(self.pool_sums)
-            self._all_reduce(self.pool_counts)
         rho = float(cfg["proto_rho"])
-        call("diga_proto_update", _p(self.pool_sums), _p(self.pool_counts), Cn, FEAT_CH, _p(self.inst_proto), _p(self.inst_flag),
-             _p(self.run_proto), _p(self.run_flag), _p(self.state_flag), float(np.float32(1 - rho)), float(np.float32(rho)),
-             _stream())
         pl, fl = float(cfg["proto_lambda"]), float(cfg["fusion_lambda"])
-        call("diga_proto_classify_fuse", _p(self.feat), _p(self.logits), _p(self.inst_proto), _p(self.inst_flag),
-             _p(self.run_proto), _p(self.run_flag), _p(self.probs), B, Cn, self.hw, FEAT_CH, 1.0, float(np.float32(pl)),
-             float(np.float32(1 - pl)), float(np.float32(fl)), float(np.float32(1 - fl)), _stream())
+        hw, Ps = self.hw, self.Ps
+        call("diga_nearest_down_labels", _p(y), int(y.dtype == torch.int64), _p(self.labels[hw:] if self.stream else self.labels[self.P:]),
+             B, y.shape[1], y.shape[2], self.h, self.wd, 2 * hw if self.stream else 0, _stream())
+        # batch mode: one pass over the whole batch; stream mode: one pass per frame, in stream order (the running
+        # prototypes of frame t feed frame t+1, ttda:1702-1705)
+        for s in range(B if self.stream else 1):
+            feat = self.feat[s * hw * FEAT_CH:] if self.stream else self.feat
+            labels = self.labels[s * 2 * hw:] if self.stream else self.labels
+            logits = self.logits[s:] if self.stream else self.logits
+            probs = self.probs[s:] if self.stream else self.probs
+            call("diga_proto_pool", _p(feat), _p(labels), 2, Ps, Cn, FEAT_CH, _p(self.pool_work), _p(self.pool_sums),
+                 _p(self.pool_counts), _stream())
+            if self.world > 1:
+                self._all_reduce(self.pool_sums)
+                self._all_reduce(self.pool_counts)
+            call("diga_proto_update", _p(self.pool_sums), _p(self.pool_counts), Cn, FEAT_CH, _p(self.inst_proto), _p(self.inst_flag),
+                 _p(self.run_proto), _p(self.run_flag), _p(self.state_flag), float(np.float32(1 - rho)), float(np.float32(rho)),
+                 _stream())
+            call("diga_proto_classify_fuse", _p(feat), _p(logits), _p(self.inst_proto), _p(self.inst_flag),
+                 _p(self.run_proto), _p(self.run_flag), _p(probs), 1 if self.stream else B, Cn, hw, FEAT_CH, 1.0,
+                 float(np.float32(pl)), float(np.float32(1 - pl)), float(np.float32(fl)), float(np.float32(1 - fl)), _stream())
         return self.probs
 
     def forward_and_adapt(self, x, y, cfg):
@@ -377,8 +407,15 @@ class Engine:
         H, W = y.shape[1], y.shape[2]
         if self.pred.shape != y.shape:
             self.pred = torch.empty(y.shape, dtype=torch.uint8, device=self.dev)
-        call("diga_upsample_argmax_hist", _p(self.probs), _p(y), int(y.dtype == torch.int64), _p(self.pred), _p(self.hist),
-             _p(probs_up), self.B, self.C, self.h, self.wd, H, W, _stream())
+        if not self.stream:
+            call("diga_upsample_argmax_hist", _p(self.probs), _p(y), int(y.dtype == torch.int64), _p(self.pred), _p(self.hist),
+                 _p(probs_up), self.B, self.C, self.h, self.wd, H, W, _stream())
+            return self.pred
+        # stream mode: the reference's metric sees batch-1 updates (its confusion matrix is scaled by the batch size,
+        # ttda:158-173), so every frame is its own call
+        for s in range(self.B):
+            call("diga_upsample_argmax_hist", _p(self.probs[s:]), _p(y[s:]), int(y.dtype == torch.int64), _p(self.pred[s:]),
+                 _p(self.hist), _p(probs_up[s:]) if probs_up is not None else None, 1, self.C, self.h, self.wd, H, W, _stream())
         return self.pred
 
     def reset_state(self):

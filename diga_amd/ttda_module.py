@@ -161,7 +161,7 @@ class SIFABatchNorm2dTrainable(nn.BatchNorm2d):
         y = torch.empty_like(x)
         split_b = 1 if B > 1 else B                       # half_first (ttda:313-320)
         call("diga_bn_stats_nchw_f32", _p(x), B, Cc, H * W, split_b, _p(prm[0]), _p(slab), _stream())
-        call("diga_bn_finalize", _p(slab), 1, Cc, float(split_b * H * W), float((B - split_b) * H * W), _p(prm[0]), _p(prm[1]),
+        call("diga_bn_finalize", _p(slab), 1, 2, 1, 0, Cc, float(split_b * H * W), float((B - split_b) * H * W), _p(prm[0]), _p(prm[1]),
              _p(prm[2]), _p(prm[3]), _f32(float(self.lambda_)), _f32(self.eps), _p(sc), _p(sh), _stream())
         call("diga_bn_apply_nchw_f32", _p(x), _p(sc), _p(sh), _p(y), B, Cc, H * W, _stream())
         return y
@@ -487,7 +487,7 @@ class DIGA(nn.Module):
         lg = outputs.to(self.device, torch.float32).contiguous()
         B, Cn, h, w = lg.shape
         lab = torch.empty(B * h * w, dtype=torch.int32, device=self.device)
-        call("diga_head_finish_pseudo_label", None, 1, Cn, None, _p(lg), None, _p(lab), B, Cn, h * w, _f32(threshold), _stream())
+        call("diga_head_finish_pseudo_label", None, 1, Cn, None, _p(lg), None, _p(lab), B, Cn, h * w, _f32(threshold), 0, _stream())
         return lab.reshape(B, h, w).long()
 
     def cal_proto(self, feature, y):
@@ -557,9 +557,9 @@ class DIGA(nn.Module):
         Pn = B * h * w
         labels = torch.empty(2 * Pn, dtype=torch.int32, device=dev)
         call("diga_head_finish_pseudo_label", None, 1, Cn, None, _p(lg), None, _p(labels), B, Cn, h * w,
-             _f32(cfg.confidence_threshold), _stream())
+             _f32(cfg.confidence_threshold), 0, _stream())
         call("diga_nearest_down_labels", _p(yd), int(yd.dtype == torch.int64), _p(labels[Pn:]), B, yd.shape[1], yd.shape[2], h, w,
-             _stream())
+             0, _stream())
         work = torch.empty(call("diga_proto_pool_work_bytes", 2, Pn, Cn, CH), dtype=torch.uint8, device=dev)
         sums = torch.empty(2 * Cn * CH, dtype=torch.float32, device=dev)
         counts = torch.empty(2 * Cn, dtype=torch.int32, device=dev)

@@ -51,80 +51,102 @@ typedef struct {
   int16_t dy[DIGA_MAX_TAPS];   /* tap offsets in input pixels, e.g. (kh-1)*dilation */
   int16_t dx[DIGA_MAX_TAPS];
   int32_t cout_pad;            /* rows of wgt (>= Cout, multiple of the N tile); padding rows are zero */
-  int32_t split_row;           /* rows m < split_row -> statistics group A, the rest -> group B
-                                  (the reference's half_first rule, ttda:313-320); = M for one group */
   int32_t splitk;              /* >= 1; > 1 only with out_f32 */
   int32_t out_f32;             /* 0: out = bf16 [M][Cout];  1: out = fp32 [splitk][M][cout_pad] partials */
   int32_t tile;                /* 0 = auto; else tile-config id (see diga_conv_tile_info) */
 } diga_conv_desc;
 
-/* Number of M tiles the kernel will use for `desc` (= rows of the statistics slab). */
-int diga_conv_num_mtiles(const diga_conv_desc* desc);
+/* Number of statistics units diga_conv_igemm_bf16 writes for `desc`: B * ceil(Ho*Wo / 32).  A unit is
+ * 32 consecutive output rows of ONE sample (M tiles never straddle samples), independent of the tile shape. */
+int diga_conv_stat_units(const diga_conv_desc* desc);
 
 /* in: bf16 NHWC; wgt: bf16 [cout_pad][ntaps*Cin]; out: see desc.out_f32;
- * stat_slab: NULL, or fp32 [num_mtiles][2 groups][2 (sum, sumsq)][Cout] of *shifted* values
- * (x - stat_shift[c]) taken from the fp32 accumulators; stat_shift: fp32 [Cout] (the source
- * running_mean: the shifted-data variance algorithm stays accurate when mean >> std). */
+ * stat_slab: NULL, or fp32 [stat_units][2 (sum, sumsq)][Cout] of *shifted* values (x - stat_shift[c])
+ * taken from the fp32 accumulators, sample-major; stat_shift: fp32 [Cout] (the source running_mean:
+ * the shifted-data variance algorithm stays accurate when mean >> std).  Which samples form the
+ * reference's half_first groups is decided in diga_bn_finalize, not here. */
 int diga_conv_igemm_bf16(const diga_conv_desc* desc, const void* in, const void* wgt, void* out,
                          float* stat_slab, const float* stat_shift, void* stream);
 
 /* Stem (adaptseg:133,178): 7x7 stride 2 pad 3, 3 -> 64, fp32 NCHW input [B,3,H,W] -> raw bf16 NHWC
- * [B,Ho,Wo,64] + statistics slab [num_tiles][2][2][64] (same format as above).
- * wgt: fp32 [64][3][7][7] (the reference layout).  Returns the number of slab tiles when x == NULL. */
+ * [B,Ho,Wo,64] + statistics slab [units][2][64] (sample-major, units/B per sample).
+ * wgt: fp32 [64][3][7][7] (the reference layout).  Returns the number of slab units when x == NULL. */
 int diga_stem_conv7x7s2(const float* x, const float* wgt, void* out, float* stat_slab,
-                        const float* stat_shift, int B, int H, int W, int split_row, void* stream);
+                        const float* stat_shift, int B, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * DAM batch norm (SIFABatchNorm2d.forward eval branch, ttda:299-345).
  * ------------------------------------------------------------------------------------------ */
-/* Reduce a statistics slab in fixed tile order (deterministic) and produce the per-channel affine
+/* Reduce a statistics slab in fixed unit order (deterministic) and produce the per-channel affine
  *   mean_g = K + S1_g/n_g,  var_g = S2_g/n_g - (S1_g/n_g)^2            (g = A, B; biased var)
  *   mean_cur = n_b > 0 ? (mean_A + mean_B)/2 : mean_A   (same for var)   ttda:315-320
  *   mean = lam*running_mean + (1-lam)*mean_cur, var likewise (1-lam in fp32)   ttda:335-336
  *   scale = weight / sqrt(var + eps),  shift = bias - mean*scale        ttda:341-343
- * slab: fp32 [ntiles][2][2][C]; n_a / n_b: element counts of the two groups (global counts when the
- * slab holds all-reduced sums).  scale/shift: fp32 [C]. */
-int diga_bn_finalize(const float* slab, int ntiles, int C, double n_a, double n_b,
-                     const float* running_mean, const float* running_var, const float* weight,
-                     const float* bias, float lam, float eps, float* scale, float* shift, void* stream);
+ * slab: fp32 [nsamples*units_per_sample][2][C], sample-major.
+ * per_sample == 0: the reference's batch rule (half_first): group A = the first a_samples samples,
+ *   group B = the rest; n_a / n_b = element counts of the groups; scale/shift fp32 [C].
+ * per_sample != 0: every sample is normalised with its own statistics, i.e. nsamples independent
+ *   batch-1 frames of a stream ride in one launch; n_a = elements per sample, n_b = 0;
+ *   scale/shift fp32 [nsamples][C].  Sample s's result is bit-identical to a batch-1 call. */
+int diga_bn_finalize(const float* slab, int units_per_sample, int nsamples, int a_samples,
+                     int per_sample, int C, double n_a, double n_b, const float* running_mean,
+                     const float* running_var, const float* weight, const float* bias, float lam,
+                     float eps, float* scale, float* shift, void* stream);
 
-/* Sum a slab over its tiles only: sums[2][2][C] fp32 (what the multi-GPU path all-reduces). */
-int diga_bn_reduce_slab(const float* slab, int ntiles, int C, float* sums, void* stream);
+/* Multi-GPU form of the same statistic: every rank sums ITS slab over its units into
+ * sums[2 groups][2][C] in fp64 (group A = its first a_samples samples: 1 on rank 0, 0 elsewhere), the
+ * ranks all-reduce(sum) that buffer, and diga_bn_finalize_sums turns the global sums into scale/shift
+ * with the arithmetic of diga_bn_finalize (n_a / n_b = global element counts).  fp64 keeps the
+ * exchange exact enough that a sharded batch reproduces the single-process batch bit for bit in
+ * practice (sums of exactly the same fp32 unit values, rounded to fp32 only after the division). */
+int diga_bn_reduce_slab(const float* slab, int units_per_sample, int nsamples, int a_samples, int C,
+                        double* sums, void* stream);
+int diga_bn_finalize_sums(const double* sums, int C, double n_a, double n_b, const float* running_mean,
+                          const float* running_var, const float* weight, const float* bias, float lam,
+                          float eps, float* scale, float* shift, void* stream);
 
 /* y = relu?( raw*scale + shift  [+ res_raw*res_scale + res_shift | + res] ) -> bf16 [M][C]
  * (adaptseg:86-87,90-91,94,96-100).  raw, res: bf16 [M][C]; res_scale == NULL means `res` is an
- * already-normalised activation; res == NULL means no residual. */
+ * already-normalised activation; res == NULL means no residual.  nsamples_affine == 0: one affine
+ * [C] for all rows; > 0: the M rows are that many equal samples and scale/shift (and res_scale/
+ * res_shift) are [nsamples_affine][C] (per-sample statistics, see diga_bn_finalize). */
 int diga_bn_apply(const void* raw, const float* scale, const float* shift, const void* res,
                   const float* res_scale, const float* res_shift, void* out, int64_t M, int C,
-                  int relu, void* stream);
+                  int relu, int nsamples_affine, void* stream);
 
 /* The stand-alone module form (SIFABatchNorm2dTrainable.forward on an fp32 NCHW tensor, ttda:299-345):
- * per-channel shifted sums with 64-lane wavefront-shuffle reductions -> a 1-tile slab for
- * diga_bn_finalize (group A = samples [0, split_b), group B = the rest), then y = x*scale + shift. */
+ * per-channel shifted sums with 64-lane wavefront-shuffle reductions -> slab [2 groups][2][C] for
+ * diga_bn_finalize(units_per_sample 1, nsamples 2, a_samples 1) (group A = samples [0, split_b),
+ * group B = the rest), then y = x*scale + shift. */
 int diga_bn_stats_nchw_f32(const float* x, int B, int C, int HW, int split_b, const float* stat_shift,
                            float* slab, void* stream);
 int diga_bn_apply_nchw_f32(const float* x, const float* scale, const float* shift, float* out, int B,
                            int C, int HW, void* stream);
 
 /* bn1 + ReLU + MaxPool2d(3, stride 2, pad 1, ceil_mode=True) fused (adaptseg:179-181,139):
- * raw bf16 NHWC [B,H,W,C] -> bf16 NHWC [B,Ho,Wo,C], Ho = ceil((H-1)/2)+1 (PyTorch ceil rule). */
+ * raw bf16 NHWC [B,H,W,C] -> bf16 NHWC [B,Ho,Wo,C], Ho = ceil((H-1)/2)+1 (PyTorch ceil rule).
+ * per_sample != 0: scale/shift are [B][C]. */
 int diga_bn_relu_maxpool(const void* raw, const float* scale, const float* shift, void* out, int B,
-                         int H, int W, int C, int Ho, int Wo, void* stream);
+                         int H, int W, int C, int Ho, int Wo, int per_sample, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * SAM (ttda:1662-1805) and fusion (ttda:1644)
  * ------------------------------------------------------------------------------------------ */
 /* Sum split-K head partials + bias -> logits fp32 NCHW [B,C,h,w]; softmax/argmax/threshold ->
  * pseudo-labels int32 [B*h*w] (255 = not confident; strict '<', ttda:1675) (ttda:1662-1676).
- * partials: fp32 [splitk][M][cpad] (M = B*h*w) or NULL when logits_in is given (NCHW fp32). */
+ * partials: fp32 [splitk][M][cpad] (M = B*h*w) or NULL when logits_in is given (NCHW fp32).
+ * label_sample_stride: distance in elements between the label rows of consecutive samples
+ * (0 = hw, dense); a stream of batch-1 frames keeps [pseudo | gt] per sample, i.e. stride 2*hw. */
 int diga_head_finish_pseudo_label(const float* partials, int splitk, int cpad, const float* bias_sum,
                                   const float* logits_in, float* logits_out, int32_t* labels,
-                                  int B, int C, int hw, float threshold, void* stream);
+                                  int B, int C, int hw, float threshold, int64_t label_sample_stride,
+                                  void* stream);
 
 /* F.interpolate(y.float(), size=(h,w), mode='nearest').long() (ttda:1695): src = floor(dst*in/out)
- * computed as the reference does (fp32 scale).  y: int64 (y_is_i64) or int32 [B,H,W] -> int32 [B,h,w]. */
+ * computed as the reference does (fp32 scale).  y: int64 (y_is_i64) or int32 [B,H,W] -> int32 [B,h,w];
+ * out_sample_stride as label_sample_stride above (0 = dense). */
 int diga_nearest_down_labels(const void* y, int y_is_i64, int32_t* out, int B, int H, int W, int h,
-                             int w, void* stream);
+                             int w, int64_t out_sample_stride, void* stream);
 
 /* cal_proto (ttda:1788-1805) for up to two label sets in one call.  Stable (pixel-order) per-class
  * index lists, then chunked register-accumulated row sums -- deterministic.

@@ -42,9 +42,9 @@ def run(name, tiles, reps, B=1):
         if Cout % bn:
             continue
         M = B * d.Ho * d.Wo
-        nt = call("diga_conv_num_mtiles", C.byref(d))
+        nu = call("diga_conv_stat_units", C.byref(d))
         out = torch.empty(M * Cout, dtype=torch.bfloat16, device=DEV)
-        slab = torch.empty(nt * 4 * Cout, dtype=torch.float32, device=DEV)
+        slab = torch.empty(nu * 2 * Cout, dtype=torch.float32, device=DEV)
         for _ in range(3):
             call("diga_conv_igemm_bf16", C.byref(d), P(x), P(w), P(out), P(slab), P(shift), stream())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -56,7 +56,7 @@ def run(name, tiles, reps, B=1):
         us = e0.elapsed_time(e1) * 1e3 / reps
         fl = 2.0 * M * Cout * Cin * taps
         bm = {1: 128, 2: 128, 3: 64, 4: 64, 5: 128}[tile % 10]
-        res.append((tile, us, fl / us / 1e6, nt * (Cout // bn)))
+        res.append((tile, us, fl / us / 1e6, B * -(-(d.Ho * d.Wo) // bm) * (Cout // bn)))
     best = min(res, key=lambda r: r[1])
     print(f"{name:7s} M={B * d.Ho * d.Wo:6d} K={taps * Cin:5d} N={Cout:5d} {fl / 1e9:6.2f} GF | " +
           " ".join(f"t{t}:{us:6.1f}us/{tf:4.0f}TF/{nb}b" for t, us, tf, nb in res) + f" | best t{best[0]} {best[1]:.1f}us {best[2]:.0f}TF", flush=True)

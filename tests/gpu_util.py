@@ -34,7 +34,7 @@ def from_nhwc_bf16(t: torch.Tensor, shape_nhwc) -> torch.Tensor:
     return t[:B * H * W * Cc].reshape(B, H, W, Cc).to(torch.float32).permute(0, 3, 1, 2).contiguous().cpu()
 
 
-def conv_desc(B, H, W, Cin, Cout, stride=1, k3=False, dil=1, split_row=None, tile=0, cout_pad=None):
+def conv_desc(B, H, W, Cin, Cout, stride=1, k3=False, dil=1, tile=0, cout_pad=None):
     d = ConvDesc()
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, Cin, Ho, Wo, Cout
@@ -44,7 +44,6 @@ def conv_desc(B, H, W, Cin, Cout, stride=1, k3=False, dil=1, split_row=None, til
         for t in range(9):
             d.dy[t], d.dx[t] = (t // 3 - 1) * dil, (t % 3 - 1) * dil
     d.cout_pad = cout_pad or Cout
-    d.split_row = B * Ho * Wo if split_row is None else split_row
     d.splitk, d.out_f32, d.tile = 1, 0, tile
     return d
 

@@ -28,25 +28,30 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_conv_desc_layout_matches_header():
-    # int32 x9, int16 x18 x2, int32 x5
-    assert C.sizeof(_lib.ConvDesc) == 9 * 4 + 2 * 18 * 2 + 5 * 4
+    # int32 x9, int16 x18 x2, int32 x4
+    assert C.sizeof(_lib.ConvDesc) == 9 * 4 + 2 * 18 * 2 + 4 * 4
 
 
 def test_argument_validation_needs_no_gpu():
     d = _lib.ConvDesc()
     d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 1, 9, 17, 48, 9, 17, 64
-    d.stride, d.ntaps, d.cout_pad, d.split_row, d.splitk = 1, 1, 64, 153, 1
+    d.stride, d.ntaps, d.cout_pad, d.splitk = 1, 1, 64, 1
     with pytest.raises(_lib.DigaError, match="Cin=48"):
-        _lib.call("diga_conv_num_mtiles", C.byref(d))
+        _lib.call("diga_conv_stat_units", C.byref(d))
     d.Cin = 64
-    assert _lib.call("diga_conv_num_mtiles", C.byref(d)) == 3          # 153 rows / 64
+    assert _lib.call("diga_conv_stat_units", C.byref(d)) == 5           # 153 rows / 32
+    d.B = 3
+    assert _lib.call("diga_conv_stat_units", C.byref(d)) == 15          # units never straddle samples
     d.splitk = 2                                                        # split-K needs fp32 partial output
     with pytest.raises(_lib.DigaError, match="splitk"):
-        _lib.call("diga_conv_num_mtiles", C.byref(d))
-    assert _lib.call("diga_stem_conv7x7s2", None, None, None, None, None, 1, 512, 1024, 0, None) == 64 * 8
+        _lib.call("diga_conv_stat_units", C.byref(d))
+    assert _lib.call("diga_stem_conv7x7s2", None, None, None, None, None, 1, 512, 1024, None) == 64 * 8
+    assert _lib.call("diga_stem_conv7x7s2", None, None, None, None, None, 4, 512, 1024, None) == 4 * 64 * 8
     assert _lib.call("diga_proto_pool_work_bytes", 2, 8385, 19, 2048) > 0
     with pytest.raises(_lib.DigaError):
-        _lib.call("diga_bn_apply", None, None, None, None, None, None, None, 10, 64, 1, None)
+        _lib.call("diga_bn_apply", None, None, None, None, None, None, None, 10, 64, 1, 0, None)
+    with pytest.raises(_lib.DigaError, match="a_samples"):
+        _lib.call("diga_bn_finalize", *([C.c_void_p(8)] + [4, 2, 3, 0, 64, 1.0, 1.0] + [C.c_void_p(8)] * 4 + [0.8, 1e-5] + [C.c_void_p(8)] * 2 + [None]))
 
 
 def test_feature_grid_matches_reference_shapes():

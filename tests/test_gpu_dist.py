@@ -72,22 +72,18 @@ def test_two_ranks_reproduce_batch2_semantics():
         probs = eng.forward_and_adapt(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), CFG)
         torch.cuda.synchronize()
         ref_logits, ref_probs = eng.logits.cpu().numpy(), probs.cpu().numpy()
-        nbn1 = 64        # the first BN layer's scale is untouched by any upstream rounding flip: tight check of the protocol
+        sc_ref = eng.scale.cpu().numpy()
         for r in range(2):
             got = res[r][t]
-            assert np.abs(got["scale"][:nbn1] - eng.scale.cpu().numpy()[:nbn1]).max() <= 1e-6 * np.abs(eng.scale.cpu().numpy()[:nbn1]).max()
-            rng = ref_logits.max() - ref_logits.min()
-            assert np.abs(got["logits"][0] - ref_logits[r]).max() / rng < 0.02     # same bf16 floor as the e2e tests
-            # probabilities: single pixels can move a lot when one pseudo label flips (bf16_floor.json shows max-abs up to
-            # 0.8 for the oracle's own emulation), so bound the mean and the arg-max agreement instead of the max
-            assert np.nanmean(np.abs(got["probs"][0] - ref_probs[r])) < 5e-3
-            assert (got["probs"][0].argmax(0) == ref_probs[r].argmax(0)).mean() > 0.9
+            # BN exchange: each group's fp64 sums come from one rank's units in the same order as the single-process
+            # finalize walks them, so scale/shift of all 104 layers -- and with them features and logits -- are bit-identical
+            assert np.array_equal(got["scale"], sc_ref)
+            assert np.array_equal(got["logits"][0], ref_logits[r])
+            # prototype sums are added in a different order (per-rank fp32 sums + all-reduce): fp32 rounding only
+            assert np.array_equal(np.isnan(got["probs"][0]), np.isnan(ref_probs[r]))
+            assert np.nanmax(np.abs(got["probs"][0] - ref_probs[r])) < 1e-4
             assert np.array_equal(got["rflag"], eng.run_flag.cpu().numpy())
-        # replicated SAM state is bitwise identical across ranks
+        # replicated SAM state is bitwise identical across ranks, and equal to the single-process batch up to fp32 rounding
         assert np.array_equal(res[0][t]["run"], res[1][t]["run"])
-        # vs the single-process batch: rows of classes with only a few (pseudo-labelled) pixels move a lot when one label
-        # flips through bf16 rounding, so require 80 % of the existing class rows to agree within 5 %
         ref_run = eng.run_proto.cpu().numpy()
-        rows = np.nonzero(eng.run_flag.cpu().numpy())[0]
-        rel = np.array([np.abs(res[0][t]["run"][c] - ref_run[c]).max() / max(np.abs(ref_run[c]).max(), 1e-6) for c in rows])
-        assert (rel < 0.05).mean() >= 0.8, rel
+        assert np.abs(res[0][t]["run"] - ref_run).max() <= 1e-5 * np.abs(ref_run).max()

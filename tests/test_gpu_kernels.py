@@ -60,33 +60,76 @@ def test_conv_igemm(B, H, W, Cin, Cout, stride, k3, dil, tile):
     rm, rv, bw, bb = _bn_params(Cout, g)
     ref = F.conv2d(x, wt, stride=stride, padding=dil if k3 else 0, dilation=dil if k3 else 1)
     Ho, Wo = ref.shape[2:]
-    d = conv_desc(B, H, W, Cin, Cout, stride, k3, dil, split_row=(Ho * Wo if B > 1 else None), tile=tile)
+    d = conv_desc(B, H, W, Cin, Cout, stride, k3, dil, tile=tile)
     assert (d.Ho, d.Wo) == (Ho, Wo)
     xin = to_nhwc_bf16(x)
     wp = wt.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(torch.bfloat16).to(DEV)
     out = torch.zeros(B * Ho * Wo * Cout, dtype=torch.bfloat16, device=DEV)
-    nt = call("diga_conv_num_mtiles", C.byref(d))
-    slab = torch.full((nt * 4 * Cout,), float("nan"), dtype=torch.float32, device=DEV)
+    nu = call("diga_conv_stat_units", C.byref(d))
+    ups = nu // B
+    assert nu == B * ((Ho * Wo + 31) // 32)
+    slab = torch.full((nu * 2 * Cout,), float("nan"), dtype=torch.float32, device=DEV)
     dv = [t.to(DEV) for t in (rm, rv, bw, bb)]
     call("diga_conv_igemm_bf16", C.byref(d), P(xin), P(wp), P(out), P(slab), P(dv[0]), stream())
     sc = torch.empty(Cout, dtype=torch.float32, device=DEV)
     sh = torch.empty(Cout, dtype=torch.float32, device=DEV)
     n_a = float(Ho * Wo)
     n_b = float((B - 1) * Ho * Wo)
-    call("diga_bn_finalize", P(slab), nt, Cout, n_a, n_b, P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), 0.8, 1e-5, P(sc), P(sh), stream())
+    call("diga_bn_finalize", P(slab), ups, B, 1 if B > 1 else B, 0, Cout, n_a, n_b, P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), 0.8, 1e-5,
+         P(sc), P(sh), stream())
+    # per-sample statistics (a stream of batch-1 frames riding in one launch): [B][Cout] affines
+    scp = torch.empty(B * Cout, dtype=torch.float32, device=DEV)
+    shp = torch.empty(B * Cout, dtype=torch.float32, device=DEV)
+    call("diga_bn_finalize", P(slab), ups, B, B, 1, Cout, n_a, 0.0, P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), 0.8, 1e-5,
+         P(scp), P(shp), stream())
     torch.cuda.synchronize()
+    assert not torch.isnan(slab).any()          # every unit of every sample was written
     got = from_nhwc_bf16(out, (B, Ho, Wo, Cout))
     e = rel_err(got, bf16_round(ref))
     assert e <= BF16_TOL, f"raw conv output rel err {e}"
     rsc, rsh = _oracle_scale_shift(ref, rm, rv, bw, bb)
     assert rel_err(sc.cpu(), rsc) < 1e-4 and rel_err(sh.cpu(), rsh) < 1e-4, (rel_err(sc.cpu(), rsc), rel_err(sh.cpu(), rsh))
+    for b in range(B):
+        rsc, rsh = _oracle_scale_shift(ref[b:b + 1], rm, rv, bw, bb)
+        assert rel_err(scp.cpu()[b * Cout:(b + 1) * Cout], rsc) < 1e-4 and rel_err(shp.cpu()[b * Cout:(b + 1) * Cout], rsh) < 1e-4
+
+
+def test_conv_results_do_not_depend_on_tile_or_batch():
+    """The statistics units (32 rows of one sample) and the outputs are bit-identical for every tile shape, and a
+    sample's rows/units are bit-identical whether it is computed alone or as part of a batch: this is what makes
+    stream mode (k batch-1 frames per trunk pass) exact."""
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Cin, Cout = 3, 13, 21, 128, 128
+    x = bf16_round(torch.randn(B, Cin, H, W, generator=g).relu())
+    wt = bf16_round(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.03)
+    wp = wt.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(torch.bfloat16).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+
+    def run(xs, tile):
+        b = xs.shape[0]
+        d = conv_desc(b, H, W, Cin, Cout, 1, True, 2, tile=tile)
+        nu = call("diga_conv_stat_units", C.byref(d))
+        xin = to_nhwc_bf16(xs)
+        out = torch.zeros(b * H * W * Cout, dtype=torch.bfloat16, device=DEV)
+        slab = torch.zeros(nu * 2 * Cout, dtype=torch.float32, device=DEV)
+        call("diga_conv_igemm_bf16", C.byref(d), P(xin), P(wp), P(out), P(slab), P(shift), stream())
+        torch.cuda.synchronize()
+        return out.view(torch.int16).cpu().reshape(b, -1), slab.cpu().reshape(b, -1)
+
+    o0, s0 = run(x, 23)
+    for tile in (1, 12, 24, 3, 21):
+        o, sl = run(x, tile)
+        assert torch.equal(o, o0) and torch.equal(sl.view(torch.int32), s0.view(torch.int32)), tile
+    for b in range(B):
+        o, sl = run(x[b:b + 1], 24)
+        assert torch.equal(o[0], o0[b]) and torch.equal(sl[0].view(torch.int32), s0[b].view(torch.int32)), b
 
 
 def test_conv_rejects_bad_shapes():
     from diga_amd._lib import DigaError
     d = conv_desc(1, 9, 17, 48, 64)       # Cin not a multiple of 64
     with pytest.raises(DigaError, match="Cin"):
-        call("diga_conv_num_mtiles", C.byref(d))
+        call("diga_conv_stat_units", C.byref(d))
 
 
 @pytest.mark.parametrize("B,h,w,splitk", [(1, 9, 17, 4), (2, 13, 21, 3), (1, 33, 65, 1)])
@@ -117,7 +160,7 @@ def test_head_conv_and_pseudo_labels(B, h, w, splitk):
     labels = torch.empty(Pn, dtype=torch.int32, device=DEV)
     bias = (b0 + b1).to(DEV)
     call("diga_head_finish_pseudo_label", P(part), splitk, 32, P(bias), None, P(logits), P(labels), B, NC, h * w, float(np.float32(0.9)),
-         stream())
+         0, stream())
     torch.cuda.synchronize()
     assert rel_err(logits.cpu(), ref) < 1e-4
     # pseudo labels from the GPU's own logits must match the oracle applied to those logits, except within 1e-6 of the bar
@@ -138,17 +181,16 @@ def test_stem_bn_maxpool(B, H, W):
     rm, rv, bw, bb = _bn_params(64, g)
     ref = F.conv2d(x, wt, stride=2, padding=3)
     Ho, Wo = ref.shape[2:]
-    nt = call("diga_stem_conv7x7s2", None, None, None, None, None, B, H, W, 0, None)
+    nu = call("diga_stem_conv7x7s2", None, None, None, None, None, B, H, W, None)
     out = torch.zeros(B * Ho * Wo * 64, dtype=torch.bfloat16, device=DEV)
-    slab = torch.full((nt * 4 * 64,), float("nan"), dtype=torch.float32, device=DEV)
+    slab = torch.full((nu * 2 * 64,), float("nan"), dtype=torch.float32, device=DEV)
     dv = [t.to(DEV) for t in (rm, rv, bw, bb)]
-    split = Ho * Wo if B > 1 else B * Ho * Wo
     xd, wd = x.to(DEV), wt.to(DEV)      # keep device copies alive until the kernels have run
-    call("diga_stem_conv7x7s2", P(xd), P(wd), P(out), P(slab), P(dv[0]), B, H, W, split, stream())
+    call("diga_stem_conv7x7s2", P(xd), P(wd), P(out), P(slab), P(dv[0]), B, H, W, stream())
     sc = torch.empty(64, dtype=torch.float32, device=DEV)
     sh = torch.empty(64, dtype=torch.float32, device=DEV)
-    call("diga_bn_finalize", P(slab), nt, 64, float(Ho * Wo), float((B - 1) * Ho * Wo), P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), 0.8,
-         1e-5, P(sc), P(sh), stream())
+    call("diga_bn_finalize", P(slab), nu // B, B, 1 if B > 1 else B, 0, 64, float(Ho * Wo), float((B - 1) * Ho * Wo), P(dv[0]),
+         P(dv[1]), P(dv[2]), P(dv[3]), 0.8, 1e-5, P(sc), P(sh), stream())
     torch.cuda.synchronize()
     got = from_nhwc_bf16(out, (B, Ho, Wo, 64))
     assert rel_err(got, bf16_round(ref)) <= BF16_TOL
@@ -158,11 +200,24 @@ def test_stem_bn_maxpool(B, H, W):
     from diga_amd.engine import pool_out
     Hp, Wp = pool_out(Ho), pool_out(Wo)
     pooled = torch.zeros(B * Hp * Wp * 64, dtype=torch.bfloat16, device=DEV)
-    call("diga_bn_relu_maxpool", P(out), P(sc), P(sh), P(pooled), B, Ho, Wo, 64, Hp, Wp, stream())
+    call("diga_bn_relu_maxpool", P(out), P(sc), P(sh), P(pooled), B, Ho, Wo, 64, Hp, Wp, 0, stream())
     torch.cuda.synchronize()
     y = torch.relu(got * sc.cpu()[None, :, None, None] + sh.cpu()[None, :, None, None])
     refp = F.max_pool2d(y, 3, 2, 1, ceil_mode=True)
     assert refp.shape[2:] == (Hp, Wp)
+    assert rel_err(from_nhwc_bf16(pooled, (B, Hp, Wp, 64)), bf16_round(refp)) <= BF16_TOL
+    # per-sample affines (stream mode)
+    scp = torch.empty(B * 64, dtype=torch.float32, device=DEV)
+    shp = torch.empty(B * 64, dtype=torch.float32, device=DEV)
+    call("diga_bn_finalize", P(slab), nu // B, B, B, 1, 64, float(Ho * Wo), 0.0, P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), 0.8, 1e-5,
+         P(scp), P(shp), stream())
+    call("diga_bn_relu_maxpool", P(out), P(scp), P(shp), P(pooled), B, Ho, Wo, 64, Hp, Wp, 1, stream())
+    torch.cuda.synchronize()
+    for b in range(B):
+        rsc, rsh = _oracle_scale_shift(ref[b:b + 1], rm, rv, bw, bb)
+        assert rel_err(scp.cpu()[b * 64:(b + 1) * 64], rsc) < 1e-4 and rel_err(shp.cpu()[b * 64:(b + 1) * 64], rsh) < 1e-4
+    scc, shc = scp.cpu().reshape(B, 64, 1, 1), shp.cpu().reshape(B, 64, 1, 1)
+    refp = F.max_pool2d(torch.relu(got * scc + shc), 3, 2, 1, ceil_mode=True)
     assert rel_err(from_nhwc_bf16(pooled, (B, Hp, Wp, 64)), bf16_round(refp)) <= BF16_TOL
 
 
@@ -183,9 +238,31 @@ def test_bn_apply(Cc, mode):
     out = torch.zeros(M * Cc, dtype=torch.bfloat16, device=DEV)
     rawd, resd, scd, shd, rscd, rshd = (t.to(DEV) for t in (raw.to(torch.bfloat16), res.to(torch.bfloat16), sc, sh, rsc, rsh))
     call("diga_bn_apply", P(rawd), P(scd), P(shd), P(resd) if mode else None, P(rscd) if mode == 2 else None,
-         P(rshd) if mode == 2 else None, P(out), M, Cc, 1, stream())
+         P(rshd) if mode == 2 else None, P(out), M, Cc, 1, 0, stream())
     torch.cuda.synchronize()
     assert rel_err(out.float().cpu().reshape(M, Cc), bf16_round(ref)) <= BF16_TOL
+
+
+@pytest.mark.parametrize("Cc,mode,ns", [(64, 0, 3), (512, 2, 4), (1024, 1, 2)])
+def test_bn_apply_per_sample_affine(Cc, mode, ns):
+    g = torch.Generator().manual_seed(Cc + mode + ns)
+    Ms = 419
+    raw = bf16_round(torch.randn(ns, Ms, Cc, generator=g) * 2)
+    res = bf16_round(torch.randn(ns, Ms, Cc, generator=g))
+    sc, sh = torch.rand(ns, 1, Cc, generator=g) + 0.5, torch.randn(ns, 1, Cc, generator=g)
+    rsc, rsh = torch.rand(ns, 1, Cc, generator=g) + 0.5, torch.randn(ns, 1, Cc, generator=g)
+    ref = raw * sc + sh
+    if mode == 1:
+        ref = ref + res
+    if mode == 2:
+        ref = ref + (res * rsc + rsh)
+    ref = torch.relu(ref)
+    out = torch.zeros(ns * Ms * Cc, dtype=torch.bfloat16, device=DEV)
+    rawd, resd, scd, shd, rscd, rshd = (t.contiguous().to(DEV) for t in (raw.to(torch.bfloat16), res.to(torch.bfloat16), sc, sh, rsc, rsh))
+    call("diga_bn_apply", P(rawd), P(scd), P(shd), P(resd) if mode else None, P(rscd) if mode == 2 else None,
+         P(rshd) if mode == 2 else None, P(out), ns * Ms, Cc, 1, ns, stream())
+    torch.cuda.synchronize()
+    assert rel_err(out.float().cpu().reshape(ns, Ms, Cc), bf16_round(ref)) <= BF16_TOL
 
 
 @pytest.mark.parametrize("B", [1, 2, 3])
@@ -201,7 +278,7 @@ def test_standalone_dam_bn_matches_reference_fixture(gold_bn, B):
     y = torch.empty_like(x)
     split_b = 1 if B > 1 else B
     call("diga_bn_stats_nchw_f32", P(x), Bn, Cc, H * W, split_b, P(prm[0]), P(slab), stream())
-    call("diga_bn_finalize", P(slab), 1, Cc, float(split_b * H * W), float((B - split_b) * H * W), P(prm[0]), P(prm[1]), P(prm[2]),
+    call("diga_bn_finalize", P(slab), 1, 2, 1, 0, Cc, float(split_b * H * W), float((B - split_b) * H * W), P(prm[0]), P(prm[1]), P(prm[2]),
          P(prm[3]), 0.8, 1e-5, P(sc), P(sh), stream())
     call("diga_bn_apply_nchw_f32", P(x), P(sc), P(sh), P(y), Bn, Cc, H * W, stream())
     torch.cuda.synchronize()

@@ -212,6 +212,39 @@ def test_run_to_run_determinism(weights):
         assert torch.equal(torch.nan_to_num(a.float(), nan=-1.0), torch.nan_to_num(b.float(), nan=-1.0))
 
 
+@pytest.mark.parametrize("H,W,K", [(129, 257, 3), (512, 1024, 4)])
+def test_stream_mode_is_bit_identical_to_batch1_steps(weights, H, W, K):
+    """K frames in flight (one trunk pass with per-sample DAM statistics, SAM frame by frame) == K separate batch-1
+    steps, bit for bit: probabilities, logits, features, predictions, confusion matrix and the SAM state; two windows
+    so that the running prototypes cross a window boundary.  Tile shapes differ between the two engines (auto rule on
+    M), which the tile-independent statistics units make irrelevant."""
+    e1 = Engine(weights, 1, H, W)
+    ek = Engine(weights, K, H, W, stream=True)
+    for win in range(2):
+        xs, ys = zip(*[synth.synth_frame(win * K + t, 1, H, W) for t in range(K)])
+        seq = []
+        for t in range(K):
+            yd = torch.from_numpy(ys[t]).cuda()
+            p = e1.forward_and_adapt(torch.from_numpy(xs[t]).cuda(), yd, CFG)
+            e1.tail(yd)
+            torch.cuda.synchronize()
+            seq.append((p.cpu().clone(), e1.logits.cpu().clone(), e1.feat.view(torch.int16).cpu().clone(), e1.pred.cpu().clone()))
+        xk = torch.from_numpy(np.concatenate(xs)).cuda()
+        yk = torch.from_numpy(np.concatenate(ys)).cuda()
+        pk = ek.forward_and_adapt(xk, yk, CFG)
+        ek.tail(yk)
+        torch.cuda.synchronize()
+        fk = ek.feat.view(torch.int16).cpu().reshape(K, -1)
+        for t in range(K):
+            assert torch.equal(fk[t], seq[t][2].reshape(-1)), ("feat", win, t)
+            assert torch.equal(ek.logits[t].cpu(), seq[t][1][0]), ("logits", win, t)
+            a, b = pk[t].cpu(), seq[t][0][0]
+            assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), ("probs", win, t)
+            assert torch.equal(ek.pred[t].cpu(), seq[t][3][0]), ("pred", win, t)
+        assert torch.equal(ek.run_proto.cpu(), e1.run_proto.cpu()) and torch.equal(ek.run_flag.cpu(), e1.run_flag.cpu())
+        assert bool((ek.hist == e1.hist).all()), ("hist", win)
+
+
 def test_reference_api_surface(diga):
     """Return types / shapes / state semantics of the mirrored API (ttda:1599-1645, 1702-1705)."""
     m = diga

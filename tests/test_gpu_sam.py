@@ -28,7 +28,7 @@ def test_pseudo_labels_fixture(gold_sam):
     lg = T(gold_sam["pl_logits"]).to(DEV)
     B, C_, h, w = lg.shape
     lab = torch.empty(B * h * w, dtype=torch.int32, device=DEV)
-    call("diga_head_finish_pseudo_label", None, 1, C_, None, P(lg), None, P(lab), B, C_, h * w, float(np.float32(0.9)), stream())
+    call("diga_head_finish_pseudo_label", None, 1, C_, None, P(lg), None, P(lab), B, C_, h * w, float(np.float32(0.9)), 0, stream())
     torch.cuda.synchronize()
     got = lab.cpu().numpy().reshape(B, h, w)
     want = gold_sam["pl_labels"]
@@ -152,8 +152,8 @@ def test_multi_proto_label_sequence_fixture(gold_sam, B):
         _, _, h, w = feat.shape
         Pn = B * h * w
         labels = torch.empty(2 * Pn, dtype=torch.int32, device=DEV)
-        call("diga_head_finish_pseudo_label", None, 1, NC, None, P(lg), None, P(labels), B, NC, h * w, f32(0.9), stream())
-        call("diga_nearest_down_labels", P(y), 1, P(labels[Pn:]), B, y.shape[1], y.shape[2], h, w, stream())
+        call("diga_head_finish_pseudo_label", None, 1, NC, None, P(lg), None, P(labels), B, NC, h * w, f32(0.9), 0, stream())
+        call("diga_nearest_down_labels", P(y), 1, P(labels[Pn:]), B, y.shape[1], y.shape[2], h, w, 0, stream())
         f = to_nhwc_bf16(feat)
         work = torch.empty(call("diga_proto_pool_work_bytes", 2, Pn, NC, CH), dtype=torch.uint8, device=DEV)
         sums = torch.empty(2 * NC * CH, dtype=torch.float32, device=DEV)
@@ -177,7 +177,7 @@ def test_nearest_down_fixture(gold_tail):
         for dt in (torch.int64, torch.int32):
             y = T(g[f"nd_{n}_y"].astype(np.int64)).to(dt).to(DEV)
             out = torch.empty(h * w, dtype=torch.int32, device=DEV)
-            call("diga_nearest_down_labels", P(y), int(dt == torch.int64), P(out), 1, H, W, h, w, stream())
+            call("diga_nearest_down_labels", P(y), int(dt == torch.int64), P(out), 1, H, W, h, w, 0, stream())
             torch.cuda.synchronize()
             assert np.array_equal(out.cpu().numpy().reshape(1, h, w), g[f"nd_{n}_ys"])
 
