@@ -78,6 +78,7 @@ def main():
                     help="N=1 only: consecutive batch-1 frames of the stream processed per step (one trunk pass with per-sample DAM "
                          "statistics, SAM frame by frame; bit-identical to one-frame steps, tests/test_gpu_net.py)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-autotune", action="store_true", help="fixed tile rule instead of timing the tile candidates per conv shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump", default=None, help="write the per-conv timing table to this JSON file")
@@ -100,7 +101,7 @@ def main():
     H, W = args.height, args.width
     weights = NetWeights(synth.synth_params(0), dev)
     fif = args.frames_in_flight if world == 1 else 1
-    eng = Engine(weights, fif, H, W, bn_lambda=CFG["bn_lambda"], group=group, stream=fif > 1)
+    eng = Engine(weights, fif, H, W, bn_lambda=CFG["bn_lambda"], group=group, stream=fif > 1, autotune=not args.no_autotune)
     nf = 4 if fif == 1 else 2
     frames = []
     for i in range(nf):
@@ -161,7 +162,7 @@ def main():
                                              "bit-identical to one-frame steps)" if fif > 1 else "; one frame per step") if world == 1 else
                                 f"BASELINE configs[2]: global batch {world} = 1 frame per GPU, BN sum/sumsq + prototype sums all-reduced (RCCL)"),
                    "resolution": f"{W}x{H}", "feature_grid": f"{eng.wd}x{eng.h}", "weights": "seeded synthetic init (diga_amd/synth.py)",
-                   "launch": "hipGraph replay" if use_graph else "eager", "includes": "net + SAM + fusion + upsample/argmax/confusion tail",
+                   "launch": "hipGraph replay" if use_graph else "eager", "conv_tiles": "autotuned per shape" if eng.autotune else "fixed rule", "includes": "net + SAM + fusion + upsample/argmax/confusion tail",
                    "frames_per_step": fif, "conv_gflop_per_frame": round(eng.conv_flops / fif / 1e9, 3)},
     }
     if rank == 0 and world == 1 and not args.no_roofline:

@@ -48,7 +48,8 @@ SIGNATURES = {
     "diga_proto_pool_work_bytes": (_i64, [_i, _i64, _i, _i]),
     "diga_proto_pool": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "diga_proto_update": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp]),
-    "diga_proto_classify_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp]),
+    "diga_proto_classify_work_bytes": (_i64, [_i64, _i]),
+    "diga_proto_classify_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp]),
     "diga_upsample_argmax_hist": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "diga_nhwc_bf16_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "diga_nchw_f32_to_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp]),

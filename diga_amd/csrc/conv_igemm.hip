@@ -4,23 +4,25 @@
 //   GEMM view:  D[m][n] = sum_k A[m][k] * Wt[n][k]
 //     m = output pixel (n_img, oh, ow)            M = B*Ho*Wo
 //     n = output channel                           N = Cout
-//     k = (tap, ci)                                K = ntaps*Cin, one 64-wide K step never crosses a tap
+//     k = (ci chunk, tap, ci % 64)                 K = ntaps*Cin, one 64-wide K step = one tap of one 64-channel chunk
 //   A is gathered on the fly (im2col never materialised): row m, tap t reads the 128-byte channel
 //   slab of input pixel (oh*stride+dy[t], ow*stride+dx[t]) or zeros outside the image.  Out-of-image
 //   and out-of-range rows are produced by the buffer-descriptor range check (offset >= num_records
 //   returns 0), so the gather is branch-free.
 //
-// Block = 256 threads = 4 waves (WM x WN), tile BM x BN x 64, LDS double-buffered with register
-// staging (global loads for step k+1 are issued before the MFMAs of step k and written to the other
-// LDS buffer after them: one barrier per K step).  LDS rows are 128 B (64 bf16); the 16-byte chunk
-// index is XOR-swizzled with (row>>1)&7 so that the ds_read_b128 fragment reads of 32 consecutive
-// rows are bank-conflict free.
+// Block = 4 or 8 waves (WM x WN), tile BM x BN x 64.  The K loop is an S-deep LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4, no register staging) with counted vmcnt and one raw s_barrier per K step.
+// LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with (row>>1)&7 -- on the SOURCE
+// address, because the DMA writes a lane-linear image -- so that the ds_read_b128 fragment reads of 32
+// consecutive rows are bank-conflict free.
 //
-// Epilogue: (1) DAM statistics -- per-channel sum / sum of squares of (x - shift[c]) taken from the
-// fp32 accumulators (columns live on lanes, rows in registers, so the reduction is 16 adds + one
-// cross-half shuffle + a tiny LDS reduce over the M-waves) written to a per-M-tile slab that
-// diga_bn_finalize sums in fixed order (deterministic, no atomics);  (2) the raw output is staged
-// through LDS and stored as 16-byte NHWC rows.
+// M tiles never straddle samples (tile -> (sample, tile in sample)), so a sample's rows are computed the same
+// way whatever batch it rides in.
+//
+// Epilogue: (1) DAM statistics -- per-channel sum / sum of squares of (x - shift[c]) taken from the fp32
+// accumulators, one "unit" per 32-row MFMA block (columns live on lanes, rows in registers: 16 adds + one
+// cross-half shuffle), written to a slab that diga_bn_finalize sums in fixed order (deterministic, no atomics,
+// independent of the tile shape);  (2) the raw output is staged through LDS and stored as 16-byte NHWC rows.
 #include "common.h"
 
 namespace {
@@ -45,16 +47,20 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int S, bool OUT_F32, bool STATS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
+template <int BM, int BN, int WM, int WN, int S, int BK, bool OUT_F32, bool STATS>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKParams p) {
+  constexpr int NW = WM * WN, NTHR = 64 * NW;        // 4 or 8 waves
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
-  constexpr int A_CH = BM / 32, B_CH = BN / 32;      // LDS-DMA wave-instructions per wave per K step
+  // K step = BK channels (64 or 32): LDS rows of ROWB bytes = CPRW 16-byte chunks; one 1-KiB LDS-DMA wave-instruction
+  // covers RPI rows.  BK = 32 halves the stage, so twice as many stages (loads in flight) fit the same LDS.
+  constexpr int ROWB = BK * 2, CPRW = BK / 8, RPI = 64 / CPRW;
+  constexpr int A_CH = BM / (RPI * NW), B_CH = BN / (RPI * NW);   // LDS-DMA wave-instructions per wave per K step
   constexpr int LPT = A_CH + B_CH;                   // loads per tile per wave (the vmcnt unit)
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
   // S = LDS ring depth; S-1 K steps of loads stay in flight
   constexpr int D = S - 1;
-  static_assert(WM * WN == 4 && MT >= 1 && NT >= 1 && S >= 2 && S <= 4, "bad tile");
+  static_assert((NW == 4 || NW == 8) && (BK == 64 || BK == 32) && MT >= 1 && NT >= 1 && A_CH >= 1 && B_CH >= 1 && S >= 2 && S <= 4, "bad tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ONLY LDS object (cdna guide 5, trap 4a)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -80,19 +86,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   const int ks_end = min(ks_begin + p.nk_per_split, p.nk_total);
   const int nt = ks_end - ks_begin;
 
-  // ---- gather state.  One LDS-DMA wave-instruction (global_load_lds_dwordx4) writes 1 KiB = 8 tile rows of
-  // 128 B, lane l -> row (l>>3), 16-byte slot (l&7).  The LDS image is lane-linear, so the XOR swizzle is
-  // applied on the SOURCE: slot s of row r holds channel chunk s ^ ((r>>1)&7) (cdna guide 5.4 rule 21).
-  // Wave w owns row groups w, w+4, ... (rows 8w + 32i + (l>>3)); those rows are fixed for the whole K loop.
-  const int lrow = 8 * wave + (lane >> 3);
-  const int cch = (lane & 7) ^ ((lrow >> 1) & 7);    // channel chunk this lane fetches ((row>>1)&7 is i-invariant)
+  // ---- gather state.  One LDS-DMA wave-instruction (global_load_lds_dwordx4) writes 1 KiB = RPI tile rows of
+  // ROWB bytes, lane l -> row l / CPRW, 16-byte slot l % CPRW.  The LDS image is lane-linear, so the XOR swizzle is
+  // applied on the SOURCE: slot s of row r holds channel chunk s ^ swz(r), swz(r) = (r>>1)&7 for 128-byte rows,
+  // (r>>2)&3 for 64-byte rows: 16 consecutive rows then cover all 16 bank quads (cdna guide 5.4 rule 21).
+  // Wave w owns row groups w, w+NW, ... (rows RPI*(w + NW*i) + l/CPRW); those rows are fixed for the whole K loop.
+  const int lrow = RPI * wave + lane / CPRW;
+  const int cch = (lane % CPRW) ^ (BK == 64 ? (lrow >> 1) & 7 : (lrow >> 2) & 3);   // swz is i-invariant
   const unsigned short* const in = reinterpret_cast<const unsigned short*>(p.in);
   const unsigned short* const wgt = reinterpret_cast<const unsigned short*>(p.wgt);
   const unsigned short* const zero = reinterpret_cast<const unsigned short*>(g_zero16);
   int pixoff[A_CH], ih0[A_CH], iw0[A_CH];
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
-    const int rem = r0 + lrow + 32 * i;
+    const int rem = r0 + lrow + RPI * NW * i;
     if (rem < p.hw) {
       const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
       ih0[i] = oh * p.stride;
@@ -106,13 +113,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
   }
   int wrow_off[B_CH];
 #pragma unroll
-  for (int j = 0; j < B_CH; ++j) wrow_off[j] = (n0 + lrow + 32 * j) * p.K + cch * 8;
+  for (int j = 0; j < B_CH; ++j) wrow_off[j] = (n0 + lrow + RPI * NW * j) * p.K + cch * 8;
 
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
   auto issue_tile = [&](int ks, int stage) {
-    const int kk = ks * 64;
-    const int tap = kk / p.Cin, c0 = kk - tap * p.Cin;
+    // K order = [channel chunk][tap][64]: the ntaps steps of one 64-channel chunk run back to back, so the taps'
+    // overlapping pixel lines are re-read while they are still in L2 (a 3x3 tile touches ~3x, not 9x, its rows)
+    const int kk = ks * BK;
+    const int q = BK == 64 ? ks : ks >> 1;           // index of the 64-wide (chunk, tap) step
+    const int chunk = q / p.ntaps, tap = q - chunk * p.ntaps, c0 = chunk * 64 + (BK == 64 ? 0 : (ks & 1) * 32);
     const int dd = p.dydx[tap];
     const int dy = dd >> 16, dx = (int)(short)(dd & 0xffff);
     const int tapoff = (dy * p.W + dx) * p.Cin + c0;
@@ -122,11 +132,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     for (int i = 0; i < A_CH; ++i) {
       const bool ok = (unsigned)(ih0[i] + dy) < (unsigned)p.H && (unsigned)(iw0[i] + dx) < (unsigned)p.W;
       const unsigned short* src = ok ? in + (pixoff[i] + tapoff) : zero;
-      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(dA + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(dA + i * NW * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_CH; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_ptr)(wgt + (wrow_off[j] + kk)), (lds_ptr)(dB + j * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(wgt + (wrow_off[j] + kk)), (lds_ptr)(dB + j * NW * 1024), 16, 0, 0);
   };
 
   f32x16 acc[MT][NT];
@@ -137,8 +147,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int fr_swz = (l31 >> 1) & 7;
-  const int fa_row = (wm * WTM + l31) * 128, fb_row = A_BYTES + (wn * WTN + l31) * 128;
+  const int fr_swz = BK == 64 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
+  const int fa_row = (wm * WTM + l31) * ROWB, fb_row = A_BYTES + (wn * WTN + l31) * ROWB;
 
   // ---- K loop: S-deep LDS ring filled by LDS-DMA, one raw barrier per K step, counted vmcnt so that up to
   // D = S-1 tiles stay in flight across the barrier (never __syncthreads(): its fence drains vmcnt to 0).
@@ -157,13 +167,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     const unsigned char* bA = smem + stage * STAGE_BYTES + fa_row;
     const unsigned char* bB = smem + stage * STAGE_BYTES + fb_row;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < BK / 16; ++s) {
       const int coff = ((2 * s + hh) ^ fr_swz) << 4;
       bf16x8 fa[MT], fb[NT];
 #pragma unroll
-      for (int a = 0; a < MT; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(bA + a * 4096 + coff);
+      for (int a = 0; a < MT; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(bA + a * 32 * ROWB + coff);
 #pragma unroll
-      for (int b = 0; b < NT; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(bB + b * 4096 + coff);
+      for (int b = 0; b < NT; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(bB + b * 32 * ROWB + coff);
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -247,8 +257,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
     unsigned short* out = reinterpret_cast<unsigned short*>(p.out);
     constexpr int CPR = BN / 8;                       // 16-byte chunks per tile row
 #pragma unroll
-    for (int i = 0; i < BM * CPR / 256; ++i) {
-      const int id = tid + 256 * i;
+    for (int i = 0; i < BM * CPR / NTHR; ++i) {
+      const int id = tid + NTHR * i;
       const int row = id / CPR, cc = id - row * CPR;
       const int rem = r0 + row, c = n0 + cc * 8;
       if (rem < p.hw && c < p.Cout)
@@ -258,13 +268,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKParams p) {
 }
 
 struct TileCfg {
-  int id, BM, BN, S;
+  int id, BM, BN, S, BK = 64;
 };
-// id = shape + 10*(4 - ring depth).  shape 1: 128x128, 2: 128x64, 3: 64x64, 4: 64x128, 5: 128x32 (head).
+// id = shape + 10*(4 - ring depth).  shape 1: 128x128, 2: 128x64, 3: 64x64, 4: 64x128, 5: 128x32 (head); 8-wave blocks:
+// 6: 256x128, 7: 128x256, 8: 256x256 (ring depth 2 only).  ids 31..38: the same shapes with 32-channel K steps and a 4-deep
+// ring (same LDS as 64-channel steps with 2 buffers, but three stages of loads in flight).
 // LDS per block = S*(BM+BN)*128 B, so the ring depth also sets how many blocks share a CU (160 KiB).
 const TileCfg kTiles[] = {{1, 128, 128, 4}, {11, 128, 128, 3}, {21, 128, 128, 2}, {2, 128, 64, 4}, {12, 128, 64, 3}, {22, 128, 64, 2},
                           {3, 64, 64, 4},   {13, 64, 64, 3},   {23, 64, 64, 2},   {4, 64, 128, 4}, {14, 64, 128, 3}, {24, 64, 128, 2},
-                          {5, 128, 32, 4},  {15, 128, 32, 3},  {25, 128, 32, 2}};
+                          {5, 128, 32, 4},  {15, 128, 32, 3},  {25, 128, 32, 2},  {16, 256, 128, 3}, {26, 256, 128, 2}, {17, 128, 256, 3},
+                          {27, 128, 256, 2}, {28, 256, 256, 2},
+                          {31, 128, 128, 4, 32}, {32, 128, 64, 4, 32}, {33, 64, 64, 4, 32}, {34, 64, 128, 4, 32}, {36, 256, 128, 4, 32},
+                          {37, 128, 256, 4, 32}, {38, 256, 256, 4, 32}};
 
 const TileCfg* find_tile(int id) {
   for (const auto& t : kTiles)
@@ -278,31 +293,29 @@ int auto_tile(const diga_conv_desc* d) {
   // M = 8385..33153 rows the loop is bound by what one CU can pull from L2 (~60-70 GB/s), not by MFMA issue, and
   // several small co-resident blocks per CU (2-deep ring, 32-48 KB LDS) beat one big block with a deep ring.
   if (d->cout_pad % 64 != 0) return 25;
-  auto blocks = [&](int bm, int bn) { return (int64_t)cdiv(M, bm) * cdiv(d->cout_pad, bn) * d->splitk; };
-  if (d->cout_pad % 128 == 0 && blocks(128, 128) >= 2048) return 21;   // big batches: 128x128, 2 blocks / CU
-  if (d->cout_pad % 128 == 0 && d->cout_pad >= 512) return 24;         // 64x128
-  return 23;                                                           // 64x64
+  if (d->cout_pad % 128 == 0 && (d->cout_pad >= 512 || M >= 16000)) return 24;   // 64x128
+  return 23;                                                                      // 64x64
 }
 
-template <int BM, int BN, int WM, int WN, int S>
+template <int BM, int BN, int WM, int WN, int S, int BK = 64>
 int launch_cfg(const ConvKParams& p, int splitk, bool out_f32, bool stats, hipStream_t st) {
-  constexpr int main_bytes = S * (BM + BN) * 128;
+  constexpr int main_bytes = S * (BM + BN) * BK * 2;
   constexpr int epi_bytes = BM * BN * 2;
   constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
-  dim3 grid(p.mtiles * p.ntiles_n, splitk), block(256);
+  dim3 grid(p.mtiles * p.ntiles_n, splitk), block(64 * WM * WN);
   static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, BK, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, BK, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, BK, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   if (out_f32 && !stats)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, true, false>), grid, block, smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, BK, true, false>), grid, block, smem, st, p);
   else if (!out_f32 && stats)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, false, true>), grid, block, smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, BK, false, true>), grid, block, smem, st, p);
   else if (!out_f32 && !stats)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, false, false>), grid, block, smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, BK, false, false>), grid, block, smem, st, p);
   else {
     diga_set_error("diga_conv_igemm_bf16: statistics with fp32 split-K output are not supported");
     return DIGA_EINVAL;
@@ -358,7 +371,7 @@ extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, con
   p.hw = d->Ho * d->Wo;
   p.tiles_per_sample = cdiv(p.hw, t->BM);
   p.units_per_sample = cdiv(p.hw, 32);
-  p.nk_total = p.K / 64;
+  p.nk_total = p.K / t->BK;
   p.nk_per_split = cdiv(p.nk_total, d->splitk);
   p.mtiles = d->B * p.tiles_per_sample;
   p.ntiles_n = d->cout_pad / t->BN;
@@ -381,6 +394,18 @@ extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, con
     DIGA_TILE_CASES(3, 64, 64, 2, 2)
     DIGA_TILE_CASES(4, 64, 128, 2, 2)
     DIGA_TILE_CASES(5, 128, 32, 4, 1)
+    case 16: e = launch_cfg<256, 128, 4, 2, 3>(p, d->splitk, f32, stats, st); break;
+    case 26: e = launch_cfg<256, 128, 4, 2, 2>(p, d->splitk, f32, stats, st); break;
+    case 17: e = launch_cfg<128, 256, 2, 4, 3>(p, d->splitk, f32, stats, st); break;
+    case 27: e = launch_cfg<128, 256, 2, 4, 2>(p, d->splitk, f32, stats, st); break;
+    case 28: e = launch_cfg<256, 256, 2, 4, 2>(p, d->splitk, f32, stats, st); break;
+    case 31: e = launch_cfg<128, 128, 2, 2, 4, 32>(p, d->splitk, f32, stats, st); break;
+    case 32: e = launch_cfg<128, 64, 2, 2, 4, 32>(p, d->splitk, f32, stats, st); break;
+    case 33: e = launch_cfg<64, 64, 2, 2, 4, 32>(p, d->splitk, f32, stats, st); break;
+    case 34: e = launch_cfg<64, 128, 2, 2, 4, 32>(p, d->splitk, f32, stats, st); break;
+    case 36: e = launch_cfg<256, 128, 4, 2, 4, 32>(p, d->splitk, f32, stats, st); break;
+    case 37: e = launch_cfg<128, 256, 2, 4, 4, 32>(p, d->splitk, f32, stats, st); break;
+    case 38: e = launch_cfg<256, 256, 2, 4, 4, 32>(p, d->splitk, f32, stats, st); break;
   }
 #undef DIGA_TILE_CASES
   if (e) return e;

@@ -203,33 +203,53 @@ __global__ void proto_flags_kernel(const int32_t* __restrict__ counts, int C, fl
 
 // ---------------------------------------------------------------------------------------------
 // prototype-distance classifier x2 + blend + softmax fusion (ttda:1707-1709, 1712-1734, 1644)
-// Block = 32 pixels.  Channel loop in chunks of 64: the pixel tile (fp32, pitch 65) and the 2C
-// prototypes (padded to 40 rows, stored [ch][8 groups][8] so a thread reads its 5 classes with one
-// b128 + one b32 broadcast read) are staged in LDS; thread (pix = t&31, grp = t>>5) accumulates the
-// squared distance to its 5 prototypes directly: sum (p - f)^2 in fp32, no ||f||^2-2fp+||p||^2
-// expansion (absolute error in d would be relative error in exp(-d)).
+// Squared distances are accumulated directly, sum (p - f)^2 in fp32 -- no ||f||^2 - 2 f.p + ||p||^2 expansion
+// (an absolute error in d is a relative error in exp(-d)) -- so this is fp32 VALU work: P x 2C x CH x 2 ops.
+//   1. proto_dist_kernel: block = 64 pixels x 40 prototype slots (slot k < C: instance class k, C <= k < 2C:
+//      running class k-C) x one slice of CH/PCF_SPLIT channels; 128 threads, thread = 4 pixels x 5 slots in
+//      registers: per channel one b128 read of 4 pixel values ([ch][px] image) and one b128 + b32 broadcast read
+//      of 5 prototype values feed 40 VALU ops.  Partial d^2 -> work[split][P][40].
+//   2. proto_fuse_kernel: thread = pixel: d^2 = sum of the slices in fixed order, exp(-d), flags, normalise x2,
+//      blends, softmax fusion; 0/0 -> NaN kept.
 // ---------------------------------------------------------------------------------------------
-constexpr int PCF_PIX = 32;
+constexpr int PCF_PIX = 64;
 constexpr int PCF_SLOTS = 40;
+constexpr int PCF_SPLIT = 8;
+constexpr int PCF_PITCH = 68;     // floats per channel row of the pixel image (64 + 4: keeps b128 alignment)
 
-__global__ __launch_bounds__(256) void proto_classify_fuse_kernel(const unsigned short* __restrict__ feat,
-                                                                  const float* __restrict__ logits,
-                                                                  const float* __restrict__ inst_proto,
-                                                                  const float* __restrict__ inst_flag,
-                                                                  const float* __restrict__ run_proto,
-                                                                  const float* __restrict__ run_flag, float* __restrict__ out,
-                                                                  int64_t P, int C, int hw, int CH, float tau, float pl, float pl1,
-                                                                  float fl, float fl1) {
-  __shared__ float sf[PCF_PIX][65];
-  __shared__ __attribute__((aligned(16))) float spr[64][8][8];   // [ch][grp][5 used of 8]
-  __shared__ float sd[PCF_PIX][PCF_SLOTS + 1];
-  const int tid = threadIdx.x, pix = tid & 31, grp = tid >> 5;
+// prototypes -> protoT[ch][8 slot groups][8] fp32 (5 used per group): the image proto_dist_kernel copies into LDS
+__global__ void proto_transpose_kernel(const float* __restrict__ inst_proto, const float* __restrict__ run_proto,
+                                       float* __restrict__ protoT, int C, int CH) {
+  const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (ch, padded slot)
+  if (e >= CH * 64) return;
+  const int ch = e >> 6, g = (e >> 3) & 7, j = e & 7, k = g * 5 + j;
+  float v = 0.f;
+  if (j < 5) {
+    if (k < C)
+      v = inst_proto[(size_t)k * CH + ch];
+    else if (k < 2 * C)
+      v = run_proto[(size_t)(k - C) * CH + ch];
+  }
+  protoT[e] = v;
+}
+
+__global__ __launch_bounds__(128) void proto_dist_kernel(const unsigned short* __restrict__ feat, const float* __restrict__ protoT,
+                                                         float* __restrict__ work, int64_t P, int CH, int ch_per_split) {
+  __shared__ __attribute__((aligned(16))) float sf[64][PCF_PITCH];   // [ch][px]
+  __shared__ __attribute__((aligned(16))) float spr[64][8][8];       // [ch][slot group][5 used of 8]
+  const int tid = threadIdx.x, pg = tid & 15, sg = tid >> 4;
   const int64_t p0 = (int64_t)blockIdx.x * PCF_PIX;
-  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int ch0 = 0; ch0 < CH; ch0 += 64) {
+  const int chb = blockIdx.y * ch_per_split;
+  float acc[4][5];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[i][k] = 0.f;
+  for (int ch0 = chb; ch0 < chb + ch_per_split; ch0 += 64) {
     __syncthreads();
-    {  // feature tile: 32 px x 64 ch = 256 octets, one per thread
-      const int r = tid >> 3, o = tid & 7;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {            // feature tile: 64 px x 8 octets, 4 per thread; 8 lanes read one 128-B row
+      const int id = tid + 128 * j, r = id >> 3, o = id & 7;
       float f[8];
       if (p0 + r < P) {
         unpack_bf16x8(*reinterpret_cast<const u32x4*>(feat + (size_t)(p0 + r) * CH + ch0 + o * 8), f);
@@ -238,57 +258,87 @@ __global__ __launch_bounds__(256) void proto_classify_fuse_kernel(const unsigned
         for (int i = 0; i < 8; ++i) f[i] = 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sf[r][o * 8 + i] = f[i];
+      for (int i = 0; i < 8; ++i) sf[o * 8 + i][r] = f[i];
     }
-    for (int e = tid; e < PCF_SLOTS * 64; e += 256) {   // prototypes: slot k = instance class k (k < C), running class k-C
-      const int ch = e & 63, k = e >> 6;
-      float v = 0.f;
-      if (k < C)
-        v = inst_proto[(size_t)k * CH + ch0 + ch];
-      else if (k < 2 * C)
-        v = run_proto[(size_t)(k - C) * CH + ch0 + ch];
-      spr[ch][k / 5][k % 5] = v;
+    {                                          // prototype image of these 64 channels: straight 16 KB copy
+      const f32x4* src = reinterpret_cast<const f32x4*>(protoT + (size_t)ch0 * 64);
+      f32x4* dst = reinterpret_cast<f32x4*>(&spr[0][0][0]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[tid + 128 * j] = src[tid + 128 * j];
     }
     __syncthreads();
-#pragma unroll 8
+#pragma unroll 4
     for (int ch = 0; ch < 64; ++ch) {
-      const float f = sf[pix][ch];
-      const f32x4 q = *reinterpret_cast<const f32x4*>(&spr[ch][grp][0]);
-      const float q4 = spr[ch][grp][4];
-      float d;
-      d = q[0] - f; acc[0] = fmaf(d, d, acc[0]);
-      d = q[1] - f; acc[1] = fmaf(d, d, acc[1]);
-      d = q[2] - f; acc[2] = fmaf(d, d, acc[2]);
-      d = q[3] - f; acc[3] = fmaf(d, d, acc[3]);
-      d = q4 - f;   acc[4] = fmaf(d, d, acc[4]);
-    }
-  }
+      const f32x4 f = *reinterpret_cast<const f32x4*>(&sf[ch][pg * 4]);
+      const f32x4 q = *reinterpret_cast<const f32x4*>(&spr[ch][sg][0]);
+      const float q4 = spr[ch][sg][4];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) sd[pix][grp * 5 + i] = acc[i];
-  __syncthreads();
-  if (tid < PCF_PIX && p0 + tid < P) {
-    const int64_t p = p0 + tid;
-    const int64_t b = p / hw, px = p - b * hw;
-    float wi[DIGA_NUM_CLASSES_MAX], wr[DIGA_NUM_CLASSES_MAX], l[DIGA_NUM_CLASSES_MAX];
-    float si = 0.f, sr = 0.f, mx = -INFINITY;
-    for (int c = 0; c < C; ++c) {
-      wi[c] = expf(-sqrtf(sd[tid][c]) / tau) * inst_flag[c];
-      wr[c] = expf(-sqrtf(sd[tid][C + c]) / tau) * run_flag[c];
-      si += wi[c];
-      sr += wr[c];
-      l[c] = logits[((size_t)b * C + c) * hw + px];
-      mx = fmaxf(mx, l[c]);
-    }
-    float se = 0.f;
-    for (int c = 0; c < C; ++c) {
-      l[c] = expf(l[c] - mx);
-      se += l[c];
-    }
-    for (int c = 0; c < C; ++c) {
-      const float multi = pl * (wr[c] / sr) + pl1 * (wi[c] / si);     // ttda:1709 (0/0 -> NaN kept)
-      out[((size_t)b * C + c) * hw + px] = multi * fl + (l[c] / se) * fl1;   // ttda:1644
+      for (int i = 0; i < 4; ++i) {
+        float d;
+        d = q[0] - f[i]; acc[i][0] = fmaf(d, d, acc[i][0]);
+        d = q[1] - f[i]; acc[i][1] = fmaf(d, d, acc[i][1]);
+        d = q[2] - f[i]; acc[i][2] = fmaf(d, d, acc[i][2]);
+        d = q[3] - f[i]; acc[i][3] = fmaf(d, d, acc[i][3]);
+        d = q4 - f[i];   acc[i][4] = fmaf(d, d, acc[i][4]);
+      }
     }
   }
+  float* w = work + (size_t)blockIdx.y * P * PCF_SLOTS;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t p = p0 + pg * 4 + i;
+    if (p < P) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) w[p * PCF_SLOTS + sg * 5 + k] = acc[i][k];
+    }
+  }
+}
+
+// Block = PFU_PX pixels.  Phase 1: thread (pixel, slot) sums the channel slices of its squared distance (coalesced over
+// slots) and forms exp(-d/tau)*flag; threads (pixel, class) fetch the logits.  Phase 2: thread (pixel, class) normalises
+// both prototype classifiers and the softmax over the classes in fixed order (redundantly per class: 19 LDS reads) and
+// writes its fused probability.
+constexpr int PFU_PX = 6;
+
+__global__ __launch_bounds__(256) void proto_fuse_kernel(const float* __restrict__ work, const float* __restrict__ logits,
+                                                         const float* __restrict__ inst_flag, const float* __restrict__ run_flag,
+                                                         float* __restrict__ out, int64_t P, int C, int hw, int nsplit, float tau,
+                                                         float pl, float pl1, float fl, float fl1) {
+  __shared__ float sw[PFU_PX][PCF_SLOTS];
+  __shared__ float sl[PFU_PX][DIGA_NUM_CLASSES_MAX];
+  const int tid = threadIdx.x;
+  const int64_t p0 = (int64_t)blockIdx.x * PFU_PX;
+  if (tid < PFU_PX * PCF_SLOTS) {
+    const int px = tid / PCF_SLOTS, k = tid - px * PCF_SLOTS;
+    const int64_t p = p0 + px;
+    float w = 0.f;
+    if (p < P && k < 2 * C) {
+      float d = 0.f;
+      for (int s = 0; s < nsplit; ++s) d += work[((size_t)s * P + p) * PCF_SLOTS + k];
+      w = expf(-sqrtf(d) / tau) * (k < C ? inst_flag[k] : run_flag[k - C]);
+    }
+    sw[px][k] = w;
+  }
+  const int px2 = tid >> 5, c2 = tid & 31;
+  const int64_t p2 = p0 + px2;
+  const bool live = px2 < PFU_PX && c2 < C && p2 < P;
+  int64_t b = 0, pix = 0;
+  if (live) {
+    b = p2 / hw, pix = p2 - b * hw;
+    sl[px2][c2] = logits[((size_t)b * C + c2) * hw + pix];
+  }
+  __syncthreads();
+  if (!live) return;
+  float si = 0.f, sr = 0.f, mx = -INFINITY;
+  for (int c = 0; c < C; ++c) {
+    si += sw[px2][c];
+    sr += sw[px2][C + c];
+    mx = fmaxf(mx, sl[px2][c]);
+  }
+  float se = 0.f;
+  for (int c = 0; c < C; ++c) se += expf(sl[px2][c] - mx);
+  const float multi = pl * (sw[px2][C + c2] / sr) + pl1 * (sw[px2][c2] / si);     // ttda:1709 (0/0 -> NaN kept)
+  out[((size_t)b * C + c2) * hw + pix] = multi * fl + (expf(sl[px2][c2] - mx) / se) * fl1;   // ttda:1644
 }
 
 }  // namespace
@@ -376,15 +426,28 @@ extern "C" int diga_proto_update(const float* sums, const int32_t* counts, int C
   return DIGA_OK;
 }
 
+extern "C" int64_t diga_proto_classify_work_bytes(int64_t P, int CH) {
+  if (P <= 0 || CH <= 0) return DIGA_EINVAL;
+  return (int64_t)CH * 64 * 4 + (int64_t)PCF_SPLIT * P * PCF_SLOTS * 4;     // protoT + partial squared distances
+}
+
 extern "C" int diga_proto_classify_fuse(const void* feat, const float* logits, const float* inst_proto, const float* inst_flag,
-                                        const float* run_proto, const float* run_flag, float* out, int B, int C, int hw, int CH,
-                                        float tau, float pl, float pl1, float fl, float fl1, void* stream) {
-  DIGA_CHECK_ARG(feat && logits && inst_proto && inst_flag && run_proto && run_flag && out, "diga_proto_classify_fuse: NULL pointer");
-  DIGA_CHECK_ARG(B > 0 && hw > 0 && C > 0 && 2 * C <= PCF_SLOTS && CH > 0 && CH % 64 == 0, "diga_proto_classify_fuse: bad sizes (C <= 20, CH %% 64 == 0)");
+                                        const float* run_proto, const float* run_flag, float* out, void* work, int B, int C, int hw,
+                                        int CH, float tau, float pl, float pl1, float fl, float fl1, void* stream) {
+  DIGA_CHECK_ARG(feat && logits && inst_proto && inst_flag && run_proto && run_flag && out && work, "diga_proto_classify_fuse: NULL pointer");
+  DIGA_CHECK_ARG(B > 0 && hw > 0 && C > 0 && 2 * C <= PCF_SLOTS && CH > 0 && CH % 64 == 0,
+                 "diga_proto_classify_fuse: bad sizes (C <= 20, CH %% 64 == 0)");
   const int64_t P = (int64_t)B * hw;
-  hipLaunchKernelGGL(proto_classify_fuse_kernel, dim3(cdiv(P, PCF_PIX)), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned short*)feat, logits, inst_proto, inst_flag, run_proto, run_flag, out, P, C, hw, CH, tau, pl,
-                     pl1, fl, fl1);
+  int nsplit = PCF_SPLIT;                       // channel slices: the largest divisor of CH/64 that is <= PCF_SPLIT
+  while ((CH / 64) % nsplit) --nsplit;
+  hipStream_t st = (hipStream_t)stream;
+  float* protoT = (float*)work;
+  float* partial = protoT + (size_t)CH * 64;
+  hipLaunchKernelGGL(proto_transpose_kernel, dim3(cdiv(CH * 64, 256)), dim3(256), 0, st, inst_proto, run_proto, protoT, C, CH);
+  hipLaunchKernelGGL(proto_dist_kernel, dim3(cdiv(P, PCF_PIX), nsplit), dim3(128), 0, st, (const unsigned short*)feat, protoT,
+                     partial, P, CH, CH / nsplit);
+  hipLaunchKernelGGL(proto_fuse_kernel, dim3(cdiv(P, PFU_PX)), dim3(256), 0, st, (const float*)partial, logits, inst_flag, run_flag, out,
+                     P, C, hw, nsplit, tau, pl, pl1, fl, fl1);
   DIGA_CHECK_LAUNCH("diga_proto_classify_fuse");
   return DIGA_OK;
 }

@@ -54,9 +54,18 @@ def feature_grid(H, W):
 
 
 def pack_conv_weight(w: torch.Tensor, cout_pad: int | None = None) -> torch.Tensor:
-    """[Cout,Cin,kh,kw] fp32 -> [cout_pad][kh*kw*Cin] bf16 (tap-major, channel-minor), zero-padded rows."""
-    co, ci, kh, kw = w.shape
-    out = w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+    """[Cout,Cin,kh,kw] fp32 -> [cout_pad][Cin/64][kh*kw][64] bf16 (K order of diga_conv_igemm_bf16: 64-channel chunk,
+    tap, channel), zero-padded rows."""
+    return pack_taps([w], cout_pad)
+
+
+def pack_taps(ws, cout_pad: int | None = None) -> torch.Tensor:
+    """Several [Cout,Cin,kh,kw] kernels over the same input concatenated along the tap axis (the fused head)."""
+    co, ci = ws[0].shape[:2]
+    assert ci % 64 == 0 or ci < 64, ci
+    cw = min(ci, 64)
+    taps = torch.cat([w.permute(0, 2, 3, 1).reshape(co, -1, ci // cw, cw) for w in ws], 1)     # [co][tap][chunk][cw]
+    out = taps.permute(0, 2, 1, 3).reshape(co, -1)
     if cout_pad is not None and cout_pad > co:
         out = torch.cat([out, out.new_zeros(cout_pad - co, out.shape[1])], 0)
     return out.to(torch.bfloat16).contiguous()
@@ -114,8 +123,7 @@ class NetWeights:
 
         def pack_head(prefix):
             w0, w1 = dev(sd[prefix + ".conv2d_list.0.weight"]), dev(sd[prefix + ".conv2d_list.1.weight"])
-            hw = torch.cat([w0.permute(0, 2, 3, 1).reshape(num_classes, -1), w1.permute(0, 2, 3, 1).reshape(num_classes, -1)], 1)
-            hw = torch.cat([hw, hw.new_zeros(self.head_cpad - num_classes, hw.shape[1])], 0).to(torch.bfloat16).contiguous()
+            hw = pack_taps([w0, w1], self.head_cpad)
             return hw, (dev(sd[prefix + ".conv2d_list.0.bias"]) + dev(sd[prefix + ".conv2d_list.1.bias"])).contiguous()
 
         self.head_w, self.head_bias = pack_head("layer6")
@@ -126,7 +134,8 @@ class Engine:
     """Static plan + buffers for one input shape (B, H, W) on the current device."""
 
     def __init__(self, weights: NetWeights, B: int, H: int, W: int, bn_lambda: float = 0.8, group=None,
-                 head_splitk: int = 4, confidence_threshold: float = 0.9, stream: bool = False, conv_tile: int = 0):
+                 head_splitk: int = 4, confidence_threshold: float = 0.9, stream: bool = False, conv_tile: int = 0,
+                 autotune: bool = False):
         """stream=False: x is ONE batch of B samples -> the reference's batch semantics (half_first DAM statistics over
         the batch, prototypes pooled over the batch).  stream=True: x holds B CONSECUTIVE batch-1 frames of a stream
         ("frames in flight"): the trunk runs once over all of them with per-sample DAM statistics (DAM carries no
@@ -135,6 +144,11 @@ class Engine:
         _lib.load()
         self.stream = bool(stream)
         self.conv_tile = conv_tile
+        # autotune: the first (eager) pass times the tile candidates of every distinct conv shape on the real buffers and
+        # keeps the fastest.  Outputs and statistics are bit-identical for every tile shape
+        # (tests/test_gpu_kernels.py::test_conv_results_do_not_depend_on_tile_or_batch), so this never changes results.
+        self.autotune = bool(autotune) and conv_tile == 0
+        self.tile_cache = {}
         assert not (stream and group is not None), "stream mode pipelines frames on one GPU; shard batches instead"
         self.w = weights
         self.dev = weights.device
@@ -188,6 +202,7 @@ class Engine:
         self.Ps = self.hw if self.stream else self.P             # pixels one SAM pass pools over
         self.pool_work = torch.empty(int(_lib.load().diga_proto_pool_work_bytes(2, self.Ps, self.C, FEAT_CH)),
                                      dtype=torch.uint8, device=dev)
+        self.pcf_work = torch.empty(int(_lib.load().diga_proto_classify_work_bytes(self.Ps, FEAT_CH)), dtype=torch.uint8, device=dev)
         self.pool_sums = torch.zeros(2 * self.C * FEAT_CH, dtype=f32, device=dev)
         self.pool_counts = torch.zeros(2 * self.C, dtype=i32, device=dev)
         self.inst_proto = torch.zeros(self.C, FEAT_CH, dtype=f32, device=dev)
@@ -261,12 +276,39 @@ class Engine:
         d.cout_pad = Cout
         d.splitk, d.out_f32, d.tile = 1, 0, self.conv_tile
         flops = 2 * self.B * Ho * Wo * Cout * Cin * d.ntaps
+        if self.autotune:
+            key = (Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3)
+            if key not in self.tile_cache and not torch.cuda.is_current_stream_capturing():
+                self.tile_cache[key] = self._tune(d, x, self.w.conv[name], out, bn)
+            d.tile = self.tile_cache.get(key, 0)
         ev = self._ev_start()
         call("diga_conv_igemm_bf16", C.byref(d), _p(x), _p(self.w.conv[name]), _p(out), _p(self.slab), _p(bn.running_mean),
              _stream())
         self._ev_end(ev, name, flops)
         self.conv_flops += flops
         return (Ho * Wo + 31) // 32          # statistics units per sample
+
+    TILE_CANDIDATES = {23: 64, 13: 64, 22: 64, 12: 64, 24: 128, 14: 128, 21: 128, 26: 128, 16: 128, 27: 256, 17: 256, 28: 256,
+                       33: 64, 32: 64, 34: 128, 31: 128, 36: 128, 37: 256, 38: 256}   # id -> N tile
+
+    def _tune(self, d, x, wgt, out, bn, reps=3):
+        best, best_t = 0, float("inf")
+        for tile, bn_tile in self.TILE_CANDIDATES.items():
+            if d.cout_pad % bn_tile:
+                continue
+            d.tile = tile
+            evs = []
+            for r in range(reps + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                call("diga_conv_igemm_bf16", C.byref(d), _p(x), _p(wgt), _p(out), _p(self.slab), _p(bn.running_mean), _stream())
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            t = min(a.elapsed_time(b) for a, b in evs[1:])
+            if t < best_t:
+                best, best_t = tile, t
+        return best
 
     def _ev_start(self):
         if self.conv_events is None:
@@ -393,7 +435,7 @@ class Engine:
                  _p(self.run_proto), _p(self.run_flag), _p(self.state_flag), float(np.float32(1 - rho)), float(np.float32(rho)),
                  _stream())
             call("diga_proto_classify_fuse", _p(feat), _p(logits), _p(self.inst_proto), _p(self.inst_flag),
-                 _p(self.run_proto), _p(self.run_flag), _p(probs), 1 if self.stream else B, Cn, hw, FEAT_CH, 1.0,
+                 _p(self.run_proto), _p(self.run_flag), _p(probs), _p(self.pcf_work), 1 if self.stream else B, Cn, hw, FEAT_CH, 1.0,
                  float(np.float32(pl)), float(np.float32(1 - pl)), float(np.float32(fl)), float(np.float32(1 - fl)), _stream())
         return self.probs
 

@@ -520,8 +520,9 @@ class DIGA(nn.Module):
         fl = exists_flag.to(self.device, torch.float32).contiguous()
         zeros = torch.zeros(B, Cn, h, w, dtype=torch.float32, device=self.device)
         out = torch.empty_like(zeros)
-        call("diga_proto_classify_fuse", _p(f), _p(zeros), _p(pr), _p(fl), _p(pr), _p(fl), _p(out), B, Cn, h * w, CH, float(tau), 1.0,
-             0.0, 1.0, 0.0, _stream())
+        work = torch.empty(call("diga_proto_classify_work_bytes", B * h * w, CH), dtype=torch.uint8, device=self.device)
+        call("diga_proto_classify_fuse", _p(f), _p(zeros), _p(pr), _p(fl), _p(pr), _p(fl), _p(out), _p(work), B, Cn, h * w, CH,
+             float(tau), 1.0, 0.0, 1.0, 0.0, _stream())
         return out
 
     def _update_classifier_proto(self, feature, y, classifier_proto, classifier_proto_exists_flag, rho=None):
@@ -576,8 +577,9 @@ class DIGA(nn.Module):
         zeros = torch.zeros(B, Cn, h, w, dtype=torch.float32, device=dev)
         out = torch.empty_like(zeros)
         pl = float(cfg.proto_lambda)
-        call("diga_proto_classify_fuse", _p(f), _p(zeros), _p(inst), _p(iflag), _p(self._run_proto), _p(self._run_flag), _p(out), B,
-             Cn, h * w, CH, 1.0, _f32(pl), _f32(1 - pl), 1.0, 0.0, _stream())
+        cwork = torch.empty(call("diga_proto_classify_work_bytes", Pn, CH), dtype=torch.uint8, device=dev)
+        call("diga_proto_classify_fuse", _p(f), _p(zeros), _p(inst), _p(iflag), _p(self._run_proto), _p(self._run_flag), _p(out),
+             _p(cwork), B, Cn, h * w, CH, 1.0, _f32(pl), _f32(1 - pl), 1.0, 0.0, _stream())
         return out, {}
 
     # ---- BN replacement (ttda:1808-1833)

@@ -60,7 +60,7 @@ typedef struct {
  * 32 consecutive output rows of ONE sample (M tiles never straddle samples), independent of the tile shape. */
 int diga_conv_stat_units(const diga_conv_desc* desc);
 
-/* in: bf16 NHWC; wgt: bf16 [cout_pad][ntaps*Cin]; out: see desc.out_f32;
+/* in: bf16 NHWC; wgt: bf16 [cout_pad][Cin/64][ntaps][64] (K order = channel chunk, tap, channel); out: see desc.out_f32;
  * stat_slab: NULL, or fp32 [stat_units][2 (sum, sumsq)][Cout] of *shifted* values (x - stat_shift[c])
  * taken from the fp32 accumulators, sample-major; stat_shift: fp32 [Cout] (the source running_mean:
  * the shifted-data variance algorithm stays accurate when mean >> std).  Which samples form the
@@ -167,11 +167,13 @@ int diga_proto_update(const float* sums, const int32_t* counts, int C, int CH, f
 
 /* cal_pred_of_proto x2 + proto blend + softmax fusion (ttda:1707-1709,1712-1734,1644):
  *   out = fl*(pl*P_run + pl1*P_inst) + fl1*softmax(logits),  P_x[c] = exp(-||proto_x[c]-f||)*flag/sum
- * 0/0 -> NaN is reproduced.  feat bf16 [P][CH]; logits fp32 NCHW [B,C,hw]; out fp32 NCHW [B,C,hw]. */
+ * 0/0 -> NaN is reproduced.  feat bf16 [P][CH] (CH % 64 == 0); logits fp32 NCHW [B,C,hw]; out fp32 NCHW
+ * [B,C,hw]; work: scratch of diga_proto_classify_work_bytes(P = B*hw, CH) bytes (prototype image + partial squared distances). */
+int64_t diga_proto_classify_work_bytes(int64_t P, int CH);
 int diga_proto_classify_fuse(const void* feat, const float* logits, const float* inst_proto,
                              const float* inst_flag, const float* run_proto, const float* run_flag,
-                             float* out, int B, int C, int hw, int CH, float tau, float pl, float pl1,
-                             float fl, float fl1, void* stream);
+                             float* out, void* work, int B, int C, int hw, int CH, float tau, float pl,
+                             float pl1, float fl, float fl1, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tail (ttda:1610, 158-173): bilinear upsample (align_corners=False) + argmax + confusion matrix.

@@ -25,7 +25,8 @@ SHAPES = {
     "l4.c1a": (65, 129, 1024, 512, 1, False, 1), "l4.c1": (65, 129, 2048, 512, 1, False, 1), "l4.c2": (65, 129, 512, 512, 1, True, 4),
     "l4.c3": (65, 129, 512, 2048, 1, False, 1), "l4.ds": (65, 129, 1024, 2048, 1, False, 1),
 }
-ALL_TILES = [1, 11, 21, 2, 12, 22, 3, 13, 23, 4, 14, 24]
+ALL_TILES = [1, 11, 21, 2, 12, 22, 3, 13, 23, 4, 14, 24, 16, 26, 17, 27, 28, 31, 32, 33, 34, 36, 37, 38]
+TILE_MN = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (64, 128), 5: (128, 32), 6: (256, 128), 7: (128, 256), 8: (256, 256)}
 
 
 def run(name, tiles, reps, B=1):
@@ -38,7 +39,7 @@ def run(name, tiles, reps, B=1):
     res = []
     for tile in tiles:
         d = conv_desc(B, H, W, Cin, Cout, stride, k3, dil, tile=tile)
-        bn = {1: 128, 2: 64, 3: 64, 4: 128, 5: 32}[tile % 10]
+        bm, bn = TILE_MN[tile % 10]
         if Cout % bn:
             continue
         M = B * d.Ho * d.Wo
@@ -55,7 +56,6 @@ def run(name, tiles, reps, B=1):
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
         fl = 2.0 * M * Cout * Cin * taps
-        bm = {1: 128, 2: 128, 3: 64, 4: 64, 5: 128}[tile % 10]
         res.append((tile, us, fl / us / 1e6, B * -(-(d.Ho * d.Wo) // bm) * (Cout // bn)))
     best = min(res, key=lambda r: r[1])
     print(f"{name:7s} M={B * d.Ho * d.Wo:6d} K={taps * Cin:5d} N={Cout:5d} {fl / 1e9:6.2f} GF | " +

@@ -66,11 +66,17 @@ def test_feature_grid_matches_reference_shapes():
 
 
 def test_weight_packing_layout():
-    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3)
+    """[cout_pad][Cin/64][tap][64]: the K order of diga_conv_igemm_bf16 (include/diga_hip.h)."""
+    w = torch.arange(2 * 128 * 3 * 3, dtype=torch.float32).reshape(2, 128, 3, 3) % 251       # bf16-exact integers
     p = pack_conv_weight(w, cout_pad=4)
-    assert p.shape == (4, 27) and p.dtype == torch.bfloat16
-    assert float(p[1, (1 * 3 + 2) * 3 + 0]) == float(w[1, 0, 1, 2])   # [co][kh][kw][ci]
+    assert p.shape == (4, 9 * 128) and p.dtype == torch.bfloat16
+    q = p.float().reshape(4, 2, 9, 64)
+    for co, ci, kh, kw in [(1, 0, 1, 2), (0, 70, 2, 0), (1, 127, 0, 1)]:
+        assert float(q[co, ci // 64, kh * 3 + kw, ci % 64]) == float(w[co, ci, kh, kw])
     assert p[2:].abs().sum() == 0
+    from diga_amd.engine import pack_taps
+    h = pack_taps([w, w + 1], 4).float().reshape(4, 2, 18, 64)                                 # fused head: taps of branch 2 follow
+    assert float(h[1, 1, 9 + 4, 5]) == float(w[1, 69, 1, 1] + 1) and float(h[1, 1, 4, 5]) == float(w[1, 69, 1, 1])
 
 
 def _diga():

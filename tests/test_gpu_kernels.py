@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from gpu_util import DEV, P, bf16_round, call, conv_desc, from_nhwc_bf16, rel_err, stream, to_nhwc_bf16
+from diga_amd.engine import pack_conv_weight, pack_taps
 from oracle import diga_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -63,7 +64,7 @@ def test_conv_igemm(B, H, W, Cin, Cout, stride, k3, dil, tile):
     d = conv_desc(B, H, W, Cin, Cout, stride, k3, dil, tile=tile)
     assert (d.Ho, d.Wo) == (Ho, Wo)
     xin = to_nhwc_bf16(x)
-    wp = wt.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(torch.bfloat16).to(DEV)
+    wp = pack_conv_weight(wt).to(DEV)
     out = torch.zeros(B * Ho * Wo * Cout, dtype=torch.bfloat16, device=DEV)
     nu = call("diga_conv_stat_units", C.byref(d))
     ups = nu // B
@@ -99,10 +100,10 @@ def test_conv_results_do_not_depend_on_tile_or_batch():
     sample's rows/units are bit-identical whether it is computed alone or as part of a batch: this is what makes
     stream mode (k batch-1 frames per trunk pass) exact."""
     g = torch.Generator().manual_seed(11)
-    B, H, W, Cin, Cout = 3, 13, 21, 128, 128
+    B, H, W, Cin, Cout = 3, 13, 21, 128, 256
     x = bf16_round(torch.randn(B, Cin, H, W, generator=g).relu())
     wt = bf16_round(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.03)
-    wp = wt.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(torch.bfloat16).to(DEV)
+    wp = pack_conv_weight(wt).to(DEV)
     shift = torch.randn(Cout, generator=g).to(DEV)
 
     def run(xs, tile):
@@ -117,7 +118,7 @@ def test_conv_results_do_not_depend_on_tile_or_batch():
         return out.view(torch.int16).cpu().reshape(b, -1), slab.cpu().reshape(b, -1)
 
     o0, s0 = run(x, 23)
-    for tile in (1, 12, 24, 3, 21):
+    for tile in (1, 12, 24, 3, 21, 26, 16, 27, 17, 28, 31, 32, 33, 34, 36, 37, 38):
         o, sl = run(x, tile)
         assert torch.equal(o, o0) and torch.equal(sl.view(torch.int32), s0.view(torch.int32)), tile
     for b in range(B):
@@ -150,8 +151,7 @@ def test_head_conv_and_pseudo_labels(B, h, w, splitk):
         for t in range(9):
             d.dy[br * 9 + t], d.dx[br * 9 + t] = (t // 3 - 1) * dil, (t % 3 - 1) * dil
     d.splitk, d.out_f32 = splitk, 1
-    hw = torch.cat([w0.permute(0, 2, 3, 1).reshape(NC, -1), w1.permute(0, 2, 3, 1).reshape(NC, -1)], 1)
-    hw = torch.cat([hw, torch.zeros(32 - NC, hw.shape[1])], 0).to(torch.bfloat16).to(DEV)
+    hw = pack_taps([w0, w1], 32).to(DEV)
     Pn = B * h * w
     part = torch.full((splitk * Pn * 32,), float("nan"), dtype=torch.float32, device=DEV)
     fd = to_nhwc_bf16(feat)

@@ -114,7 +114,8 @@ def _classify(feat_nchw, logits, ip, ifl, rp, rfl, pl=0.8, fl=0.8):
     out = torch.empty(B, NC, h, w, dtype=torch.float32, device=DEV)
     f32 = lambda v: float(np.float32(v))
     keep = [to_nhwc_bf16(feat_nchw)] + [t.to(DEV) for t in (logits, ip, ifl, rp, rfl)]   # alive until synchronize()
-    call("diga_proto_classify_fuse", *(P(t) for t in keep), P(out), B, NC, h * w, CH, 1.0, f32(pl), f32(1 - pl), f32(fl), f32(1 - fl),
+    cwork = torch.empty(call("diga_proto_classify_work_bytes", B * h * w, CH), dtype=torch.uint8, device=DEV)
+    call("diga_proto_classify_fuse", *(P(t) for t in keep), P(out), P(cwork), B, NC, h * w, CH, 1.0, f32(pl), f32(1 - pl), f32(fl), f32(1 - fl),
          stream())
     torch.cuda.synchronize()
     return out.cpu()
@@ -162,7 +163,8 @@ def test_multi_proto_label_sequence_fixture(gold_sam, B):
         call("diga_proto_update", P(sums), P(counts), NC, CH, P(inst), P(iflag), P(run), P(rflag), P(state), f32(1 - 0.1), f32(0.1),
              stream())
         out = torch.empty(B, NC, h, w, dtype=torch.float32, device=DEV)
-        call("diga_proto_classify_fuse", P(f), P(lg), P(inst), P(iflag), P(run), P(rflag), P(out), B, NC, h * w, CH, 1.0, f32(0.8),
+        cwork = torch.empty(call("diga_proto_classify_work_bytes", Pn, CH), dtype=torch.uint8, device=DEV)
+        call("diga_proto_classify_fuse", P(f), P(lg), P(inst), P(iflag), P(run), P(rflag), P(out), P(cwork), B, NC, h * w, CH, 1.0, f32(0.8),
              f32(1 - 0.8), f32(0.8), f32(1 - 0.8), stream())
         torch.cuda.synchronize()
         assert np.array_equal(rflag.cpu().numpy(), g[f"mpl{B}_{t}_rflag"]), t
