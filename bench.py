@@ -5,9 +5,11 @@ full-resolution arg-max/confusion tail) on synthetic 1024x512 frames.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch: N=1 -> BASELINE.json configs[1] (batch-1 online stream on
-one MI355X, one frame per step); N>1 -> configs[2] (global batch N = one frame per GPU, BN sum/sumsq and
-prototype sums/counts all-reduced over RCCL; weak scaling).  Inputs and labels are resident in HBM before
+A "step" is one pass of the hot path: N=1 -> BASELINE.json configs[1] (batch-1 online stream on one MI355X); by default
+6 consecutive frames of the stream are in flight per step (one trunk pass with per-sample DAM statistics, SAM frame by
+frame in order -- bit-identical to one-frame steps, which are measured too and reported as "one_frame_per_step");
+N>1 -> configs[2] (global batch N = one frame per GPU, BN sum/sumsq and prototype sums/counts all-reduced over RCCL;
+weak scaling).  Inputs and labels are resident in HBM before
 the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -67,40 +69,11 @@ def cpu_baseline(nframes_timed=2, H=512, W=1024):
                        f"confusion matrix), torch {torch.__version__} CPU")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--frames-in-flight", type=int, default=1,
-                    help="N=1 only: consecutive batch-1 frames of the stream processed per step (one trunk pass with per-sample DAM "
-                         "statistics, SAM frame by frame; bit-identical to one-frame steps, tests/test_gpu_net.py)")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
-    ap.add_argument("--no-autotune", action="store_true", help="fixed tile rule instead of timing the tile candidates per conv shape")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--dump", default=None, help="write the per-conv timing table to this JSON file")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    group = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-        group = dist.group.WORLD
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-
+def run_config(args, world, rank, dev, group, weights, fif, steps, warmup):
+    """Build an engine for `fif` frames per step, time `steps` steps -> (fps, ms_per_step, engine, frames, use_graph)."""
     from diga_amd import synth
-    from diga_amd.engine import Engine, NetWeights
+    from diga_amd.engine import Engine
     H, W = args.height, args.width
-    weights = NetWeights(synth.synth_params(0), dev)
-    fif = args.frames_in_flight if world == 1 else 1
     eng = Engine(weights, fif, H, W, bn_lambda=CFG["bn_lambda"], group=group, stream=fif > 1, autotune=not args.no_autotune)
     nf = 4 if fif == 1 else 2
     frames = []
@@ -137,11 +110,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
     barrier()
     dt = time.perf_counter() - t0
@@ -150,8 +123,46 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    ms_per_step = dt / args.steps * 1e3
-    fps = world * fif * args.steps / dt
+    return world * fif * steps / dt, dt / steps * 1e3, eng, frames, use_graph
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--frames-in-flight", type=int, default=6,
+                    help="N=1 only: consecutive batch-1 frames of the stream processed per step (one trunk pass with per-sample DAM "
+                         "statistics, SAM frame by frame in stream order; every frame's result is bit-identical to one-frame steps, "
+                         "tests/test_gpu_net.py::test_stream_mode_is_bit_identical_to_batch1_steps).  1 = one frame per step.")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-autotune", action="store_true", help="fixed tile rule instead of timing the tile candidates per conv shape")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-latency-mode", action="store_true", help="skip the extra one-frame-per-step measurement")
+    ap.add_argument("--dump", default=None, help="write the per-conv timing table to this JSON file")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        group = dist.group.WORLD
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from diga_amd import synth
+    from diga_amd.engine import NetWeights
+    H, W = args.height, args.width
+    weights = NetWeights(synth.synth_params(0), dev)
+    fif = max(1, args.frames_in_flight) if world == 1 else 1
+    fps, ms_per_step, eng, frames, use_graph = run_config(args, world, rank, dev, group, weights, fif, args.steps, args.warmup)
 
     res = {
         "metric": "adapted frames/sec DeepLabV2-R101 DIGA (DAM+SAM) 1024x512", "value": round(fps, 2), "unit": "frames/s",
@@ -162,7 +173,8 @@ def main():
                                              "bit-identical to one-frame steps)" if fif > 1 else "; one frame per step") if world == 1 else
                                 f"BASELINE configs[2]: global batch {world} = 1 frame per GPU, BN sum/sumsq + prototype sums all-reduced (RCCL)"),
                    "resolution": f"{W}x{H}", "feature_grid": f"{eng.wd}x{eng.h}", "weights": "seeded synthetic init (diga_amd/synth.py)",
-                   "launch": "hipGraph replay" if use_graph else "eager", "conv_tiles": "autotuned per shape" if eng.autotune else "fixed rule", "includes": "net + SAM + fusion + upsample/argmax/confusion tail",
+                   "launch": "hipGraph replay" if use_graph else "eager", "conv_tiles": "autotuned per shape" if eng.autotune else "fixed rule",
+                   "includes": "net + SAM + fusion + upsample/argmax/confusion tail",
                    "frames_per_step": fif, "conv_gflop_per_frame": round(eng.conv_flops / fif / 1e9, 3)},
     }
     if rank == 0 and world == 1 and not args.no_roofline:
@@ -170,14 +182,26 @@ def main():
         total_ms = float(ms.sum())
         igemm_flops = float(sum(f for _, f in meta))
         ach = igemm_flops / (total_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "conv_traffic.json")     # HBM bytes per step from PMC passes (profiles/README.md)
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic = tj.get(f"frames_in_flight_{fif}", {}).get("hbm_bytes_per_step")
         res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (all igemm launches of one step)",
                            "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                           "traffic": None, "launches_per_step": len(meta), "avg_launch_us": round(total_ms * 1e3 / len(meta), 2),
+                           "traffic": traffic, "launches_per_step": len(meta), "avg_launch_us": round(total_ms * 1e3 / len(meta), 2),
                            "kernel_ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(igemm_flops / 1e9, 3)}
         if args.dump:
             with open(args.dump, "w") as f:
                 json.dump([dict(name=n, gflop=fl / 1e9, us=float(m) * 1e3, tflops=fl / (float(m) * 1e-3) / 1e12)
                            for (n, fl), m in zip(meta, ms)], f, indent=0)
+    del eng, frames
+    if rank == 0 and world == 1 and fif > 1 and not args.no_latency_mode:
+        # the same stream with ONE frame per step (no look-ahead): the latency-bound form of configs[1]
+        f1, ms1, e1, _, _ = run_config(args, world, rank, dev, group, weights, 1, max(10, args.steps), min(args.warmup, 10))
+        res["one_frame_per_step"] = {"value": round(f1, 2), "unit": "frames/s", "ms_per_step": round(ms1, 4)}
+        del e1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:

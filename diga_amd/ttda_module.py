@@ -325,13 +325,16 @@ class DeepLabv2AdaptSeg(ResNetMulti):
         self._weights = None
         self._engines = {}
 
-    def engine(self, B, H, W) -> Engine:
+    def engine(self, B, H, W, stream: bool = False) -> Engine:
+        """Plan + buffers for one input shape.  stream=True: the B samples are B consecutive batch-1 frames of a stream
+        (per-sample DAM statistics, SAM frame by frame) instead of one batch of B."""
         dev = torch.device("cuda", torch.cuda.current_device())
         if self._weights is None:
             self._weights = NetWeights({k: v for k, v in self.state_dict().items()}, dev, self.num_classes)
-        key = (B, H, W)
+        key = (B, H, W, bool(stream))
         if key not in self._engines:
-            e = Engine(self._weights, B, H, W, bn_lambda=self._bn_lambda, group=self._group, confidence_threshold=self._threshold)
+            e = Engine(self._weights, B, H, W, bn_lambda=self._bn_lambda, group=None if stream else self._group,
+                       confidence_threshold=self._threshold, stream=stream, autotune=True)
             if self._sam_state is not None:      # all shapes share the one cross-frame state (ttda:1702-1705)
                 e.run_proto, e.run_flag, e.state_flag = self._sam_state
             self._engines[key] = e
@@ -443,6 +446,27 @@ class DIGA(nn.Module):
         self.log("test/acc", acc)
         self.test_step_global += 1
         return {"loss": loss}
+
+    def test_step_stream(self, batches, batch_idx: int, dataloader_idx: int = 0):
+        """K consecutive batch-1 test batches of the stream in ONE pass (frames in flight): the trunk runs once over the
+        K frames with per-sample DAM statistics, SAM / fusion / metric then run frame by frame in stream order.  No
+        counterpart in the reference (it has no look-ahead); every frame's outputs, the running prototypes and the metric
+        are bit-identical to K test_step calls (tests/test_gpu_net.py).  Returns the K per-frame probability maps (device)."""
+        xs, ys = [b[0] for b in batches], [b[1] for b in batches]
+        if any(int(x.shape[0]) != 1 for x in xs):
+            raise ValueError("test_step_stream pipelines batch-1 frames; use test_step for real batches")
+        x = torch.cat([t.to(self.device, torch.float32) for t in xs]).contiguous()
+        y = torch.cat([self._labels_on_device(t) for t in ys]).contiguous()
+        eng = self.net.engine(int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), stream=True)
+        self._last_engine = eng
+        probs = eng.forward_and_adapt(x, y, self.hparams.cfg)
+        eng.hist.zero_()
+        eng.tail(y)
+        self.test_acc[dataloader_idx].add_counts(eng.hist.reshape(eng.C, eng.C))
+        self.log("test/loss", torch.tensor(0.0))
+        self.log("test/acc", self.test_acc[dataloader_idx].compute())
+        self.test_step_global += len(batches)
+        return probs
 
     def _labels_on_device(self, y):
         y = y.to(self.device)

@@ -2,7 +2,7 @@
 path needs are read with PyYAML and the same keys).  Unlike the reference's evaluate() (eval_task.py:33) it passes
 `dataset_info` to the model, without which DIGA.__init__ cannot run.
 
-    python src/eval.py [frames=20] [datamodule.batch_size=1] [model.cfg.bn_lambda=0.8]
+    python src/eval.py [datamodule.frames=20] [datamodule.batch_size=1] [datamodule.frames_in_flight=4] [model.cfg.bn_lambda=0.8]
 """
 import functools
 import os
@@ -49,9 +49,19 @@ def main(argv):
         m.net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(0).items()}, strict=False)
         m._configure_bn_running_stats()
     H, W = dm["image_size"]
-    for t in range(int(dm["frames"])):
-        x, y = synth.synth_frame(t, int(dm["batch_size"]), H, W)
-        m.test_step((torch.from_numpy(x), torch.from_numpy(y), None, f"synthetic/{t}"), t)
+    bs, nfr, fif = int(dm["batch_size"]), int(dm["frames"]), int(dm.get("frames_in_flight", 1))
+    t = 0
+    while t < nfr:
+        k = min(fif, nfr - t) if bs == 1 else 1
+        batches = []
+        for j in range(k):
+            x, y = synth.synth_frame(t + j, bs, H, W)
+            batches.append((torch.from_numpy(x), torch.from_numpy(y), None, f"synthetic/{t + j}"))
+        if k > 1:                          # batch-1 stream, k frames in flight: same results as k test_step calls
+            m.test_step_stream(batches, t)
+        else:
+            m.test_step(batches[0], t)
+        t += k
     res = m.test_epoch_end()
     for i, r in res.items():
         print(f"test/acc/dataloaderr_idx_{i} {r['miou']:.5f}  dataloaderr16_idx_{i} {r['miou16']:.5f}  dataloaderr13_idx_{i} {r['miou13']:.5f}")

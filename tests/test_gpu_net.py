@@ -245,6 +245,28 @@ def test_stream_mode_is_bit_identical_to_batch1_steps(weights, H, W, K):
         assert bool((ek.hist == e1.hist).all()), ("hist", win)
 
 
+def test_module_stream_api_matches_test_step(diga):
+    """DIGA.test_step_stream (K frames in flight) leaves the same metric and SAM state as K test_step calls."""
+    m = diga
+    H, W, K = 129, 257, 3
+    frames = [synth.synth_frame(20 + t, 1, H, W) for t in range(2 * K)]
+    batches = [(torch.from_numpy(x), torch.from_numpy(y), None, None) for x, y in frames]
+    out = []
+    for mode in ("step", "stream"):
+        if hasattr(m, "classifier_running_proto"):
+            del m.classifier_running_proto
+        m.test_acc[0].reset()
+        if mode == "step":
+            for t, b in enumerate(batches):
+                m.test_step(b, t)
+        else:
+            for w in range(2):
+                m.test_step_stream(batches[w * K:(w + 1) * K], w * K)
+        torch.cuda.synchronize()
+        out.append((m.test_acc[0].hist.clone(), m.classifier_running_proto.cpu().clone(), m.classifier_running_proto_exists_flag.cpu().clone()))
+    assert bool((out[0][0] == out[1][0]).all()) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+
+
 def test_reference_api_surface(diga):
     """Return types / shapes / state semantics of the mirrored API (ttda:1599-1645, 1702-1705)."""
     m = diga
