@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round-1 profile collection on the GPU box (run from the repo root through gpurun):
+#   1. rocprofv3 --kernel-trace --stats of the bench command (hipGraph replay, 6 frames in flight)
+#   2. two separate --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass: TCC slots) of an eager 3-step run
+# Outputs land in gpurun_out/prof_r1c/; profiles/summarize.py turns them into the committed summaries.
+set -e -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/prof_r1c
+mkdir -p $O
+FIF=${FIF:-6}
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- \
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency-mode --frames-in-flight $FIF > $O/trace.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- \
+  python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency-mode --no-roofline --no-graph --frames-in-flight $FIF > $O/fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- \
+  python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency-mode --no-roofline --no-graph --frames-in-flight $FIF > $O/write.log 2>&1
+ls $O/*

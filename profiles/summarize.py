@@ -1,0 +1,39 @@
+"""Turn gpurun_out/prof_r1c (profiles/collect.sh) into the committed summaries:
+   profiles/r1c_bench_kernel_stats.csv   rocprofv3 --stats table of the bench command
+   profiles/conv_traffic.json            HBM-side bytes of the igemm launches of ONE step, from the PMC passes:
+                                         (2 x FETCH_SIZE + WRITE_SIZE) x 1024  (MI355X_MICROARCH.md, HBM: on gfx950
+                                         FETCH_SIZE tallies the 128-byte requests of 16-B/lane streams at 64 B -> x2;
+                                         WRITE_SIZE is exact for 16-B/lane stores; Infinity-Cache hits are counted,
+                                         so this is fabric-side traffic, an upper bound of true HBM bytes)."""
+import csv
+import json
+import os
+import shutil
+import sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r1c"
+fif = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+here = os.path.dirname(os.path.abspath(__file__))
+shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(here, "r1c_bench_kernel_stats.csv"))
+
+
+def last_step(path, counter, launches):
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and "conv_igemm_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    rows = rows[-launches:]
+    return sum(float(r["Counter_Value"]) for r in rows), [(r["Kernel_Name"], float(r["Counter_Value"])) for r in rows]
+
+
+L = 105                                   # 104 trunk convs + the fused head, per step
+f, fl = last_step(os.path.join(src, "fetch", "p_counter_collection.csv"), "FETCH_SIZE", L)
+w, wl = last_step(os.path.join(src, "write", "p_counter_collection.csv"), "WRITE_SIZE", L)
+out = {}
+p = os.path.join(here, "conv_traffic.json")
+if os.path.exists(p):
+    out = json.load(open(p))
+out[f"frames_in_flight_{fif}"] = {
+    "hbm_bytes_per_step": int((2 * f + w) * 1024), "fetch_size_kb_raw": f, "write_size_kb": w, "launches": L,
+    "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 over the igemm launches of the last eager step",
+}
+json.dump(out, open(p, "w"), indent=1)
+print(json.dumps(out[f"frames_in_flight_{fif}"]))
