@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--frames-in-flight", type=int, default=6,
-                    help="N=1 only: consecutive batch-1 frames of the stream processed per step (one trunk pass with per-sample DAM "
+                    help="consecutive batch-1 frames of the stream processed per step (one trunk pass with per-sample DAM "
                          "statistics, SAM frame by frame in stream order; every frame's result is bit-identical to one-frame steps, "
                          "tests/test_gpu_net.py::test_stream_mode_is_bit_identical_to_batch1_steps).  1 = one frame per step.")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
@@ -148,12 +148,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # DIGA_BENCH_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (ranks share a device and
+    # the collectives take a host round trip); the measured configuration is always nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("DIGA_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     group = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
@@ -161,7 +168,7 @@ def main():
     from diga_amd.engine import NetWeights
     H, W = args.height, args.width
     weights = NetWeights(synth.synth_params(0), dev)
-    fif = max(1, args.frames_in_flight) if world == 1 else 1
+    fif = max(1, args.frames_in_flight)
     fps, ms_per_step, eng, frames, use_graph = run_config(args, world, rank, dev, group, weights, fif, args.steps, args.warmup)
 
     res = {
@@ -171,9 +178,10 @@ def main():
         "config": {"workload": ("BASELINE configs[1]: DIGA TTA stream (DAM+SAM, 19 classes), batch 1, online per-frame prototype/BN-stat "
                                 "updates" + (f"; {fif} consecutive frames in flight per step (per-sample DAM statistics, sequential SAM; "
                                              "bit-identical to one-frame steps)" if fif > 1 else "; one frame per step") if world == 1 else
-                                f"BASELINE configs[2]: global batch {world} = 1 frame per GPU, BN sum/sumsq + prototype sums all-reduced (RCCL)"),
+                                f"BASELINE configs[2]: global batch {world} = 1 frame per GPU, BN sum/sumsq + prototype sums all-reduced (RCCL)"
+                                + (f"; {fif} consecutive global batches in flight per step (one exchange per BN layer for all of them)" if fif > 1 else "")),
                    "resolution": f"{W}x{H}", "feature_grid": f"{eng.wd}x{eng.h}", "weights": "seeded synthetic init (diga_amd/synth.py)",
-                   "launch": "hipGraph replay" if use_graph else "eager", "conv_tiles": "autotuned per shape" if eng.autotune else "fixed rule",
+                   "launch": "hipGraph replay" if use_graph else "eager", "backend": backend if world > 1 else None, "conv_tiles": "autotuned per shape" if eng.autotune else "fixed rule",
                    "includes": "net + SAM + fusion + upsample/argmax/confusion tail",
                    "frames_per_step": fif, "conv_gflop_per_frame": round(eng.conv_flops / fif / 1e9, 3)},
     }

@@ -37,8 +37,8 @@ SIGNATURES = {
     "diga_conv_igemm_bf16": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "diga_stem_conv7x7s2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "diga_bn_finalize": (_i, [_vp, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
-    "diga_bn_reduce_slab": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "diga_bn_finalize_sums": (_i, [_vp, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
+    "diga_bn_reduce_slab": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "diga_bn_finalize_sums": (_i, [_vp, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
     "diga_bn_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "diga_bn_stats_nchw_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "diga_bn_apply_nchw_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -97,17 +97,27 @@ __global__ void bn_finalize_sums_kernel(const double* __restrict__ sums, int C, 
                                         float* __restrict__ shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  sums += (size_t)blockIdx.y * 4 * C;          // blockIdx.y = set (one global batch of a stream of batches)
+  scale += (size_t)blockIdx.y * C;
+  shift += (size_t)blockIdx.y * C;
   const double s[4] = {sums[c], sums[C + c], sums[2 * C + c], sums[3 * C + c]};
   dam_affine_from_sums(s, c, n_a, n_b, rmean, rvar, weight, bias, lam, eps, scale, shift);
 }
 
 __global__ __launch_bounds__(64 * FIN_PH) void bn_reduce_slab_kernel(const float* __restrict__ slab, int ups, int nsamples,
-                                                                    int a_samples, int C, double* __restrict__ sums) {
+                                                                    int a_samples, int per_sample, int C,
+                                                                    double* __restrict__ sums) {
   __shared__ double red[FIN_PH][4][64];
   const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   double s[4];
-  slab_group_sums(slab, 0, a_samples * ups, nsamples * ups, C, c, c < C, red, s);
+  if (per_sample) {     // blockIdx.y = local sample = its own set: all of it is group A (a_samples > 0) or group B
+    const int u0 = blockIdx.y * ups, u1 = u0 + ups;
+    slab_group_sums(slab, u0, a_samples > 0 ? u1 : u0, u1, C, c, c < C, red, s);
+    sums += (size_t)blockIdx.y * 4 * C;
+  } else {
+    slab_group_sums(slab, 0, a_samples * ups, nsamples * ups, C, c, c < C, red, s);
+  }
   if (ph != 0 || c >= C) return;
 #pragma unroll
   for (int k = 0; k < 4; ++k) sums[k * C + c] = s[k];
@@ -288,23 +298,23 @@ extern "C" int diga_bn_finalize(const float* slab, int units_per_sample, int nsa
   return DIGA_OK;
 }
 
-extern "C" int diga_bn_finalize_sums(const double* sums, int C, double n_a, double n_b, const float* running_mean,
+extern "C" int diga_bn_finalize_sums(const double* sums, int nsets, int C, double n_a, double n_b, const float* running_mean,
                                      const float* running_var, const float* weight, const float* bias, float lam, float eps,
                                      float* scale, float* shift, void* stream) {
   DIGA_CHECK_ARG(sums && running_mean && running_var && weight && bias && scale && shift, "diga_bn_finalize_sums: NULL pointer");
-  DIGA_CHECK_ARG(C > 0 && n_a > 0 && n_b >= 0, "diga_bn_finalize_sums: bad sizes C=%d", C);
-  hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, C, n_a, n_b, running_mean,
+  DIGA_CHECK_ARG(nsets > 0 && C > 0 && n_a > 0 && n_b >= 0, "diga_bn_finalize_sums: bad sizes nsets=%d C=%d", nsets, C);
+  hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(cdiv(C, 256), nsets), dim3(256), 0, (hipStream_t)stream, sums, C, n_a, n_b, running_mean,
                      running_var, weight, bias, lam, eps, scale, shift);
   DIGA_CHECK_LAUNCH("diga_bn_finalize_sums");
   return DIGA_OK;
 }
 
-extern "C" int diga_bn_reduce_slab(const float* slab, int units_per_sample, int nsamples, int a_samples, int C, double* sums,
-                                   void* stream) {
+extern "C" int diga_bn_reduce_slab(const float* slab, int units_per_sample, int nsamples, int a_samples, int per_sample, int C,
+                                   double* sums, void* stream) {
   DIGA_CHECK_ARG(slab && sums && units_per_sample > 0 && nsamples > 0 && C > 0 && a_samples >= 0 && a_samples <= nsamples,
                  "diga_bn_reduce_slab: bad argument");
-  hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(cdiv(C, 64)), dim3(64 * FIN_PH), 0, (hipStream_t)stream, slab, units_per_sample,
-                     nsamples, a_samples, C, sums);
+  hipLaunchKernelGGL(bn_reduce_slab_kernel, dim3(cdiv(C, 64), per_sample ? nsamples : 1), dim3(64 * FIN_PH), 0, (hipStream_t)stream,
+                     slab, units_per_sample, nsamples, a_samples, per_sample, C, sums);
   DIGA_CHECK_LAUNCH("diga_bn_reduce_slab");
   return DIGA_OK;
 }

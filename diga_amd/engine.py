@@ -21,6 +21,7 @@ import torch
 
 from . import _lib
 from ._lib import ConvDesc, call
+from .dist import group_plan
 
 LAYERS = (3, 4, 23, 3)
 PLANES = (64, 128, 256, 512)
@@ -149,7 +150,8 @@ class Engine:
         # (tests/test_gpu_kernels.py::test_conv_results_do_not_depend_on_tile_or_batch), so this never changes results.
         self.autotune = bool(autotune) and conv_tile == 0
         self.tile_cache = {}
-        assert not (stream and group is not None), "stream mode pipelines frames on one GPU; shard batches instead"
+        # stream + group: the B local samples are this rank's frames of B consecutive GLOBAL batches (one frame per rank
+        # per batch): statistics are exchanged per batch, so every global batch keeps the reference's batch semantics
         self.w = weights
         self.dev = weights.device
         self.B, self.H, self.W = B, H, W
@@ -193,7 +195,7 @@ class Engine:
         def units(rows):
             return B * ((rows + 31) // 32)
         self.slab = buf(max(self.stem_units * 2 * 64, units(self.h2 * self.w2) * 2 * 256, units(self.h3 * self.w3) * 2 * 2048), f32)
-        self.sums = buf(4 * 2048, torch.float64)
+        self.sums = buf(4 * 2048 * self.na, torch.float64)
         # head / SAM
         self.head_part = buf(head_splitk * self.P * weights.head_cpad, f32)
         self.logits = torch.empty(B, self.C, self.h, self.wd, dtype=f32, device=dev)
@@ -203,8 +205,8 @@ class Engine:
         self.pool_work = torch.empty(int(_lib.load().diga_proto_pool_work_bytes(2, self.Ps, self.C, FEAT_CH)),
                                      dtype=torch.uint8, device=dev)
         self.pcf_work = torch.empty(int(_lib.load().diga_proto_classify_work_bytes(self.Ps, FEAT_CH)), dtype=torch.uint8, device=dev)
-        self.pool_sums = torch.zeros(2 * self.C * FEAT_CH, dtype=f32, device=dev)
-        self.pool_counts = torch.zeros(2 * self.C, dtype=i32, device=dev)
+        self.pool_sums = torch.zeros(self.na * 2 * self.C * FEAT_CH, dtype=f32, device=dev)      # per frame in stream mode
+        self.pool_counts = torch.zeros(self.na * 2 * self.C, dtype=i32, device=dev)
         self.inst_proto = torch.zeros(self.C, FEAT_CH, dtype=f32, device=dev)
         self.inst_flag = torch.zeros(self.C, dtype=f32, device=dev)
         self.run_proto = torch.zeros(self.C, FEAT_CH, dtype=f32, device=dev)
@@ -242,17 +244,25 @@ class Engine:
     def _finalize(self, bn: BNP, ups, rows_per_sample):
         """slab (this rank's B samples x ups units) -> scale/shift of one BN layer."""
         sc, sh = self._affine(bn)
-        if self.stream:
+        if self.stream and self.world == 1:
             call("diga_bn_finalize", _p(self.slab), ups, self.B, self.B, 1, bn.C, float(rows_per_sample), 0.0,
                  _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
+            return sc, sh
+        if self.stream:      # B global batches in flight, one frame of each on this rank: one exchange for all of them
+            _, n_a, n_b = group_plan(self.rank, self.world, 1, rows_per_sample)
+            sums = self.sums[:self.B * 4 * bn.C]
+            call("diga_bn_reduce_slab", _p(self.slab), ups, self.B, 1 if self.rank == 0 else 0, 1, bn.C, _p(sums), _stream())
+            self._all_reduce(sums)
+            call("diga_bn_finalize_sums", _p(sums), self.B, bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var), _p(bn.weight),
+                 _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
             return sc, sh
         split, n_a, n_b = self._groups(rows_per_sample)
         a_samples = split // rows_per_sample
         if self.world > 1:
             sums = self.sums[:4 * bn.C]
-            call("diga_bn_reduce_slab", _p(self.slab), ups, self.B, a_samples, bn.C, _p(sums), _stream())
+            call("diga_bn_reduce_slab", _p(self.slab), ups, self.B, a_samples, 0, bn.C, _p(sums), _stream())
             self._all_reduce(sums)
-            call("diga_bn_finalize_sums", _p(sums), bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var), _p(bn.weight),
+            call("diga_bn_finalize_sums", _p(sums), 1, bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var), _p(bn.weight),
                  _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
             return sc, sh
         call("diga_bn_finalize", _p(self.slab), ups, self.B, a_samples, 0, bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var),
@@ -420,20 +430,25 @@ class Engine:
         call("diga_nearest_down_labels", _p(y), int(y.dtype == torch.int64), _p(self.labels[hw:] if self.stream else self.labels[self.P:]),
              B, y.shape[1], y.shape[2], self.h, self.wd, 2 * hw if self.stream else 0, _stream())
         # batch mode: one pass over the whole batch; stream mode: one pass per frame, in stream order (the running
-        # prototypes of frame t feed frame t+1, ttda:1702-1705)
-        for s in range(B if self.stream else 1):
+        # prototypes of frame t feed frame t+1, ttda:1702-1705).  Pooling does not depend on the running state, so all
+        # frames are pooled first and (sharded) exchanged in one collective.
+        nset = B if self.stream else 1
+        SC = 2 * Cn * FEAT_CH
+        for s in range(nset):
             feat = self.feat[s * hw * FEAT_CH:] if self.stream else self.feat
             labels = self.labels[s * 2 * hw:] if self.stream else self.labels
+            call("diga_proto_pool", _p(feat), _p(labels), 2, Ps, Cn, FEAT_CH, _p(self.pool_work), _p(self.pool_sums[s * SC:]),
+                 _p(self.pool_counts[s * 2 * Cn:]), _stream())
+        if self.world > 1:
+            self._all_reduce(self.pool_sums)
+            self._all_reduce(self.pool_counts)
+        for s in range(nset):
+            feat = self.feat[s * hw * FEAT_CH:] if self.stream else self.feat
             logits = self.logits[s:] if self.stream else self.logits
             probs = self.probs[s:] if self.stream else self.probs
-            call("diga_proto_pool", _p(feat), _p(labels), 2, Ps, Cn, FEAT_CH, _p(self.pool_work), _p(self.pool_sums),
-                 _p(self.pool_counts), _stream())
-            if self.world > 1:
-                self._all_reduce(self.pool_sums)
-                self._all_reduce(self.pool_counts)
-            call("diga_proto_update", _p(self.pool_sums), _p(self.pool_counts), Cn, FEAT_CH, _p(self.inst_proto), _p(self.inst_flag),
-                 _p(self.run_proto), _p(self.run_flag), _p(self.state_flag), float(np.float32(1 - rho)), float(np.float32(rho)),
-                 _stream())
+            call("diga_proto_update", _p(self.pool_sums[s * SC:]), _p(self.pool_counts[s * 2 * Cn:]), Cn, FEAT_CH, _p(self.inst_proto),
+                 _p(self.inst_flag), _p(self.run_proto), _p(self.run_flag), _p(self.state_flag), float(np.float32(1 - rho)),
+                 float(np.float32(rho)), _stream())
             call("diga_proto_classify_fuse", _p(feat), _p(logits), _p(self.inst_proto), _p(self.inst_flag),
                  _p(self.run_proto), _p(self.run_flag), _p(probs), _p(self.pcf_work), 1 if self.stream else B, Cn, hw, FEAT_CH, 1.0,
                  float(np.float32(pl)), float(np.float32(1 - pl)), float(np.float32(fl)), float(np.float32(1 - fl)), _stream())

@@ -98,12 +98,16 @@ int diga_bn_finalize(const float* slab, int units_per_sample, int nsamples, int 
  * ranks all-reduce(sum) that buffer, and diga_bn_finalize_sums turns the global sums into scale/shift
  * with the arithmetic of diga_bn_finalize (n_a / n_b = global element counts).  fp64 keeps the
  * exchange exact enough that a sharded batch reproduces the single-process batch bit for bit in
- * practice (sums of exactly the same fp32 unit values, rounded to fp32 only after the division). */
-int diga_bn_reduce_slab(const float* slab, int units_per_sample, int nsamples, int a_samples, int C,
-                        double* sums, void* stream);
-int diga_bn_finalize_sums(const double* sums, int C, double n_a, double n_b, const float* running_mean,
-                          const float* running_var, const float* weight, const float* bias, float lam,
-                          float eps, float* scale, float* shift, void* stream);
+ * practice (sums of exactly the same fp32 unit values, rounded to fp32 only after the division).
+ * per_sample != 0 (a stream of global batches, k in flight): local sample j belongs to global batch j; its
+ * sums go to set j, sums[nsamples][2][2][C], as group A if a_samples > 0 (rank 0) else as group B;
+ * diga_bn_finalize_sums(nsets = k) then writes scale/shift [k][C]. */
+int diga_bn_reduce_slab(const float* slab, int units_per_sample, int nsamples, int a_samples,
+                        int per_sample, int C, double* sums, void* stream);
+int diga_bn_finalize_sums(const double* sums, int nsets, int C, double n_a, double n_b,
+                          const float* running_mean, const float* running_var, const float* weight,
+                          const float* bias, float lam, float eps, float* scale, float* shift,
+                          void* stream);
 
 /* y = relu?( raw*scale + shift  [+ res_raw*res_scale + res_shift | + res] ) -> bf16 [M][C]
  * (adaptseg:86-87,90-91,94,96-100).  raw, res: bf16 [M][C]; res_scale == NULL means `res` is an

@@ -13,12 +13,12 @@ CFG = dict(bn_lambda=0.8, proto_lambda=0.8, fusion_lambda=0.8, confidence_thresh
 H, W, NF = 65, 129, 2
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, k):
     import traceback
     os.makedirs("gpurun_out", exist_ok=True)
     log = open(f"gpurun_out/dist_rank{rank}.log", "w")
     try:
-        _worker_body(rank, world, port, q, log)
+        (_worker_stream if k > 1 else _worker_body)(rank, world, port, q, log, k)
     except Exception:
         traceback.print_exc(file=log)
         log.flush()
@@ -26,7 +26,7 @@ def _worker(rank, world, port, q):
         raise
 
 
-def _worker_body(rank, world, port, q, log):
+def _worker_body(rank, world, port, q, log, k):
     import torch.distributed as dist
     from diga_amd import synth
     from diga_amd.engine import Engine, NetWeights
@@ -51,20 +51,71 @@ def _worker_body(rank, world, port, q, log):
         pass
 
 
-def test_two_ranks_reproduce_batch2_semantics():
-    import torch.multiprocessing as mp
+def _worker_stream(rank, world, port, q, log, k):
+    """k global batches in flight: this rank holds its frame of each of them (Engine(stream=True, group=...))."""
+    import torch.distributed as dist
     from diga_amd import synth
     from diga_amd.engine import Engine, NetWeights
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
+    eng = Engine(w, k, H, W, group=dist.group.WORLD, stream=True)
+    xy = [synth.synth_frame(t, world, H, W) for t in range(k)]
+    x = torch.from_numpy(np.concatenate([a[rank:rank + 1] for a, _ in xy])).cuda()
+    y = torch.from_numpy(np.concatenate([b[rank:rank + 1] for _, b in xy])).cuda()
+    probs = eng.forward_and_adapt(x, y, CFG)
+    torch.cuda.synchronize()
+    print("window done", file=log, flush=True)
+    out = dict(probs=probs.cpu().numpy(), logits=eng.logits.cpu().numpy(), run=eng.run_proto.cpu().numpy(), rflag=eng.run_flag.cpu().numpy())
+    dist.barrier()
+    q.put((rank, out))
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+def _run_ranks(k):
+    import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() + 7 * k) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, k)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=90) for _ in procs)
     assert all(v is not None for v in res.values()), "a rank failed: see gpurun_out/dist_rank*.log"
     for p in procs:
         p.join(timeout=60)
+    return res
+
+
+def test_two_ranks_stream_of_global_batches():
+    """3 global batches of 2 in flight on 2 ranks (one BN exchange per layer for all of them, one prototype exchange) ==
+    the single-process batch-2 engine run batch after batch: trunk bit-identical, SAM state up to fp32 rounding."""
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    K = 3
+    res = _run_ranks(K)
+    w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
+    eng = Engine(w, 2, H, W)
+    for t in range(K):
+        x, y = synth.synth_frame(t, 2, H, W)
+        probs = eng.forward_and_adapt(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), CFG)
+        torch.cuda.synchronize()
+        for r in range(2):
+            assert np.array_equal(res[r]["logits"][t], eng.logits.cpu().numpy()[r]), (t, r)
+            a, b = res[r]["probs"][t], probs.cpu().numpy()[r]
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.nanmax(np.abs(a - b)) < 1e-4, (t, r)
+    ref_run = eng.run_proto.cpu().numpy()
+    assert np.array_equal(res[0]["run"], res[1]["run"]) and np.array_equal(res[0]["rflag"], eng.run_flag.cpu().numpy())
+    assert np.abs(res[0]["run"] - ref_run).max() <= 1e-5 * np.abs(ref_run).max()
+
+
+def test_two_ranks_reproduce_batch2_semantics():
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    res = _run_ranks(1)
     w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
     eng = Engine(w, 2, H, W)
     for t in range(NF):
