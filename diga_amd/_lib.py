@@ -51,6 +51,8 @@ SIGNATURES = {
     "diga_proto_classify_work_bytes": (_i64, [_i64, _i]),
     "diga_proto_classify_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp]),
     "diga_upsample_argmax_hist": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "diga_preprocess_image": (_i, [_vp, _i, _vp, _i, _i, _i, _d, _d, _d, _i, _vp]),
+    "diga_map_labels": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _vp]),
     "diga_nhwc_bf16_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "diga_nchw_f32_to_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
 }

@@ -117,14 +117,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
 
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
-  auto issue_tile = [&](int ks, int stage) {
-    // K order = [channel chunk][tap][64]: the ntaps steps of one 64-channel chunk run back to back, so the taps'
-    // overlapping pixel lines are re-read while they are still in L2 (a 3x3 tile touches ~3x, not 9x, its rows)
-    const int kk = ks * BK;
-    const int q = BK == 64 ? ks : ks >> 1;           // index of the 64-wide (chunk, tap) step
-    const int chunk = q / p.ntaps, tap = q - chunk * p.ntaps, c0 = chunk * 64 + (BK == 64 ? 0 : (ks & 1) * 32);
-    const int dd = p.dydx[tap];
-    const int dy = dd >> 16, dx = (int)(short)(dd & 0xffff);
+  // K steps are issued in increasing order, so (chunk, tap) advance incrementally and the tap's offset word is
+  // fetched one issue ahead (a scalar load whose latency would otherwise sit between the barrier and the DMAs).
+  // K order = [channel chunk][tap][64]: the ntaps steps of one 64-channel chunk run back to back, so the taps'
+  // overlapping pixel lines are re-read while they are still in L2 (a 3x3 tile touches ~3x, not 9x, its rows).
+  int is_ks = ks_begin;
+  int is_chunk, is_tap;
+  {
+    const int q = BK == 64 ? ks_begin : ks_begin >> 1;          // index of the 64-wide (chunk, tap) step
+    is_chunk = q / p.ntaps;
+    is_tap = q - is_chunk * p.ntaps;
+  }
+  int is_dd = p.dydx[is_tap];
+  auto issue_next = [&](int stage) {
+    const int kk = is_ks * BK;
+    const int c0 = is_chunk * 64 + (BK == 64 ? 0 : (is_ks & 1) * 32);
+    const int dy = is_dd >> 16, dx = (int)(short)(is_dd & 0xffff);
     const int tapoff = (dy * p.W + dx) * p.Cin + c0;
     unsigned char* const dA = smem + stage * STAGE_BYTES + wave * 1024;
     unsigned char* const dB = dA + A_BYTES;
@@ -137,6 +145,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
 #pragma unroll
     for (int j = 0; j < B_CH; ++j)
       __builtin_amdgcn_global_load_lds((gbl_ptr)(wgt + (wrow_off[j] + kk)), (lds_ptr)(dB + j * NW * 1024), 16, 0, 0);
+    ++is_ks;
+    if (BK == 64 || !(is_ks & 1)) {
+      if (++is_tap == p.ntaps) {
+        is_tap = 0;
+        ++is_chunk;
+      }
+      is_dd = p.dydx[is_tap];
+    }
   };
 
   f32x16 acc[MT][NT];
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
   // D = S-1 tiles stay in flight across the barrier (never __syncthreads(): its fence drains vmcnt to 0).
 #pragma unroll
   for (int s = 0; s < D; ++s)
-    if (s < nt) issue_tile(ks_begin + s, s);
+    if (s < nt) issue_next(s);
   int stage = 0, fill = D % S;
   for (int t = 0; t < nt; ++t) {
     // tile t must have landed: leave at most min(D-1, nt-1-t) younger tiles of THIS wave outstanding
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     else if (younger == 1) wait_vmcnt<(D >= 2 ? 1 : 0) * LPT>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();       // every wave's part of tile t is in LDS; everyone is done reading tile t-1
-    if (t + D < nt) issue_tile(ks_begin + t + D, fill);   // refills the buffer tile t-1 was read from
+    if (t + D < nt) issue_next(fill);   // K step t+D refills the buffer tile t-1 was read from
     const unsigned char* bA = smem + stage * STAGE_BYTES + fa_row;
     const unsigned char* bB = smem + stage * STAGE_BYTES + fb_row;
 #pragma unroll

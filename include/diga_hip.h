@@ -188,6 +188,23 @@ int diga_upsample_argmax_hist(const float* probs, const void* target, int target
                               int64_t* hist, float* probs_up, int B, int C, int h, int w, int H, int W,
                               void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Input pipeline: the arithmetic the reference's datasets apply to a decoded frame.
+ * ------------------------------------------------------------------------------------------ */
+/* BaseDataset.preprocess (src/datamodules/seg/base_dataset.py:45-52): img HWC RGB (uint8 or the
+ * reference's float32) [B,H,W,3] -> out fp32 CHW [B,3,H,W]; swap_rb != 0: channel c of the output is
+ * input channel 2-c (RGB -> BGR) minus mean[c]; swap_rb == 0: the BDD100K / Mapillary form
+ * (bdd100k.py:290: mean subtracted from unswapped RGB).  The subtraction runs in fp64 and is rounded
+ * to fp32 once, as numpy does for `float32_array -= float64_array`. */
+int diga_preprocess_image(const void* img, int img_is_u8, float* out, int B, int H, int W, double mean0,
+                          double mean1, double mean2, int swap_rb, void* stream);
+
+/* CityscapesDataSet.map_labels (cityscapes.py:50-51): out[i] = lut[(int64)ids[i]] with numpy's negative
+ * indexing; ids: uint8 (ids_kind 0), int32 (1) or the reference's float32 (2); lut: int32 [nlut] on the
+ * device; out int64 (out_is_i64) or int32; ids outside the table -> 255 (numpy would raise). */
+int diga_map_labels(const void* ids, int ids_kind, const int32_t* lut, int nlut, void* out, int out_is_i64,
+                    int64_t n, void* stream);
+
 /* Layout helpers for the Python-visible API (net(x, feat=True) returns NCHW fp32, adaptseg:188). */
 int diga_nhwc_bf16_to_nchw_f32(const void* in, float* out, int B, int HW, int C, void* stream);
 int diga_nchw_f32_to_nhwc_bf16(const float* in, void* out, int B, int HW, int C, void* stream);

@@ -350,3 +350,31 @@ def remap_baseline_keys(saved: dict, model_keys) -> dict:
 
 def to_torch(params: dict) -> dict:
     return {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k, v in params.items()}
+
+
+# ------------------------------------------------------------------------------------------------
+# Input pipeline.  numpy, as the reference's datasets are.
+# ------------------------------------------------------------------------------------------------
+def preprocess_image(image_hwc_rgb, mean, swap_rb=True):
+    """BaseDataset.preprocess (src/datamodules/seg/base_dataset.py:45-52) for swap_rb, the BDD100K / Mapillary form
+    `np.array(img) - self.mean` then `.float()` (src/datamodules/seg/bdd100k.py:290,296) otherwise.
+    float32 image, float64 mean: numpy evaluates `image -= mean` in float64 and casts the result back to float32."""
+    import numpy as np
+    image = np.asarray(image_hwc_rgb)
+    mean = np.asarray(mean, dtype=np.float64)
+    if not mean.any():
+        raise NotImplementedError("per-image-mean branch (base_dataset.py:49-51)")
+    if swap_rb:
+        image = image[:, :, ::-1]
+    out = (image.astype(np.float64) - mean).astype(np.float32)
+    return np.ascontiguousarray(out.transpose((2, 0, 1)))
+
+
+def map_labels(label_ids, label2train):
+    """CityscapesDataSet.__init__ / map_labels (src/datamodules/seg/cityscapes.py:38-41, 50-51)."""
+    import numpy as np
+    mapping = np.array(label2train, dtype=np.int64)
+    map_vector = np.zeros((mapping.shape[0],), dtype=np.int64)
+    for source_label, target_label in mapping:
+        map_vector[source_label] = target_label
+    return map_vector[np.asarray(label_ids).astype(np.int64, copy=False)]

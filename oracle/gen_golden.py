@@ -304,9 +304,39 @@ def gen_loader():
         json.dump(rec, f, indent=1)
 
 
+def gen_fn_input():
+    """Input pipeline: BaseDataset.preprocess and CityscapesDataSet.map_labels called on the reference's own classes
+    (instances made with object.__new__: their __init__ reads dataset files), info.json's label2train table."""
+    import importlib
+    import types
+    base = importlib.import_module("src.datamodules.seg.base_dataset")
+    city = importlib.import_module("src.datamodules.seg.cityscapes")
+    rng = np.random.default_rng(5)
+    out = {}
+    mean = np.array((104.00698793, 116.66876762, 122.67891434))          # ttda_datamodule.py:53
+    ds = object.__new__(base.BaseDataset)
+    ds.mean = mean
+    for tag, shape in (("a", (9, 13, 3)), ("b", (32, 64, 3))):
+        img = rng.integers(0, 256, shape).astype(np.float32)              # what _load_img returns (base_dataset.py:67)
+        out[f"img_{tag}"] = img.astype(np.uint8)
+        out[f"pre_{tag}"] = base.BaseDataset.preprocess(ds, img.copy()).copy()
+        out[f"bdd_{tag}"] = torch.from_numpy(np.array(img.astype(np.uint8)) - mean).float().permute(2, 0, 1).numpy()  # bdd100k.py:290,296
+    info = json.load(open("/root/reference/src/datamodules/seg/cityscapes_list/info.json"))
+    cs = object.__new__(city.CityscapesDataSet)
+    mapping = np.array(info["label2train"], dtype=np.int64)                # cityscapes.py:38-41 (np.int is gone in numpy 2)
+    cs.map_vector = np.zeros((mapping.shape[0],), dtype=np.int64)
+    for source_label, target_label in mapping:
+        cs.map_vector[source_label] = target_label
+    ids = rng.integers(-1, 34, (17, 23)).astype(np.float32)
+    out["label2train"] = mapping
+    out["ids"] = ids
+    out["train_ids"] = city.CityscapesDataSet.map_labels(cs, ids)
+    np.savez_compressed(os.path.join(GOLD, "fn_input.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["bn", "sam", "tail", "small", "full", "loader"]
+    which = sys.argv[1:] or ["bn", "sam", "tail", "small", "full", "loader", "input"]
     m = make_diga() if set(which) & {"sam", "tail", "small", "full"} else None
     if "bn" in which:
         gen_fn_bn()
@@ -320,4 +350,6 @@ if __name__ == "__main__":
         gen_net_full(m)
     if "loader" in which:
         gen_loader()
+    if "input" in which:
+        gen_fn_input()
     print("done", which)

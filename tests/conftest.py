@@ -45,6 +45,11 @@ def gold_full():
 
 
 @pytest.fixture(scope="session")
+def gold_input():
+    return load_golden("fn_input.npz")
+
+
+@pytest.fixture(scope="session")
 def synth_params_np():
     from diga_amd import synth
     return synth.synth_params(0)

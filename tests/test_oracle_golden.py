@@ -196,3 +196,18 @@ def test_whole_net_full_res(gold_full, synth_params_np):
         assert np.array_equal(r["hist"].numpy(), g[f"{t}_hist"])
     got = [float(O.miou(hist, k)) for k in ("default", "16", "13")]
     np.testing.assert_allclose(got, g["miou"], rtol=1e-6)
+
+
+def test_input_pipeline(gold_input):
+    """BaseDataset.preprocess / the BDD form / CityscapesDataSet.map_labels against the reference's own outputs
+    (tests/golden/fn_input.npz): bit-exact."""
+    from diga_amd import data
+    g = gold_input
+    mean = data.IMG_MEAN
+    assert np.array_equal(g["label2train"], np.array(data.CITYSCAPES_LABEL2TRAIN))      # the table shipped in diga_amd/data.py
+    for tag in ("a", "b"):
+        img = g[f"img_{tag}"]
+        assert np.array_equal(O.preprocess_image(img.astype(np.float32), mean, True), g[f"pre_{tag}"])
+        assert np.array_equal(O.preprocess_image(img, mean, False), g[f"bdd_{tag}"])
+    assert np.array_equal(O.map_labels(g["ids"], g["label2train"]), g["train_ids"])
+    assert np.array_equal(data.map_vector()[g["ids"].astype(np.int64)], g["train_ids"])
