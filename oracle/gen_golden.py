@@ -262,6 +262,27 @@ def gen_net_full(m):
     np.savez_compressed(os.path.join(GOLD, "net_full.npz"), **out)
 
 
+MULTIRES = [(720, 1280), (512, 1024), (540, 960)]          # BASELINE configs[4]: BDD, Cityscapes-size and IDD-size frames
+
+
+def gen_net_multires(m):
+    """One stream whose frame size changes (BASELINE configs[4]) without resetting the prototypes: 3 frames, B = 1.
+    logits / probs are stored as float16 (compared at the bf16 floor, ~1e-2), integers exactly."""
+    out = {}
+    frames = [synth.synth_frame(t, 1, H, W) for t, (H, W) in enumerate(MULTIRES)]
+    res, metric = run_sequence(m, frames)
+    for t, r in enumerate(res):
+        out[f"mr_{t}_x_sha"] = np.array(sha(frames[t][0]))
+        for k in ("logits", "probs"):
+            out[f"mr_{t}_{k}"] = np_(r[k]).astype(np.float16)
+        for k in ("pseudo", "run", "rflag", "hist"):
+            out[f"mr_{t}_{k}"] = np_(r[k])
+        out[f"mr_{t}_pred"] = np_(r["pred"]).astype(np.uint8)
+    out["mr_shapes"] = np.array(MULTIRES)
+    out["mr_miou"] = np.array([float(metric.compute()), float(metric.compute_iou("16")), float(metric.compute_iou("13"))])
+    np.savez_compressed(os.path.join(GOLD, "net_multires.npz"), **out)
+
+
 def gen_loader():
     """restore(): file named *baseline* with layer5.* head keys -> model layer6.* (ttda:1000-1016)."""
     p = synth.synth_params(0)
@@ -336,8 +357,8 @@ def gen_fn_input():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["bn", "sam", "tail", "small", "full", "loader", "input"]
-    m = make_diga() if set(which) & {"sam", "tail", "small", "full"} else None
+    which = sys.argv[1:] or ["bn", "sam", "tail", "small", "full", "multires", "loader", "input"]
+    m = make_diga() if set(which) & {"sam", "tail", "small", "full", "multires"} else None
     if "bn" in which:
         gen_fn_bn()
     if "sam" in which:
@@ -348,6 +369,8 @@ if __name__ == "__main__":
         gen_net_small(m)
     if "full" in which:
         gen_net_full(m)
+    if "multires" in which:
+        gen_net_multires(m)
     if "loader" in which:
         gen_loader()
     if "input" in which:

@@ -141,7 +141,7 @@ def _flags_equal_up_to_marginal(flag, ref_flag, pl, ref_pl):
     return all(int(c) in _MARGINAL for c in diff)
 
 
-def _run_gold_sequence(m, g, tag, B, H, W, nframes):
+def _run_gold_sequence(m, g, tag, B, H, W, nframes, shapes=None):
     _MARGINAL.clear()
     if hasattr(m, "classifier_running_proto"):
         del m.classifier_running_proto
@@ -150,6 +150,8 @@ def _run_gold_sequence(m, g, tag, B, H, W, nframes):
     metric.reset()
     stats = []
     for t in range(nframes):
+        if shapes is not None:
+            H, W = shapes[t]
         x, y = synth.synth_frame(t, B, H, W)
         batch = (torch.from_numpy(x), torch.from_numpy(y), None, None)
         m.test_step(batch, t)
@@ -157,14 +159,14 @@ def _run_gold_sequence(m, g, tag, B, H, W, nframes):
         torch.cuda.synchronize()
         key = (lambda k: f"{tag}_{t}_{k}") if tag else (lambda k: f"{t}_{k}")
         logits = eng.logits.cpu().numpy()
-        ref_logits = g[key("logits")]
+        ref_logits = g[key("logits")].astype(np.float32)
         pl = eng.labels[:eng.P].cpu().numpy().reshape(g[key("pseudo")].shape)
         s = dict(logit_err=float(np.abs(logits - ref_logits).max() / (ref_logits.max() - ref_logits.min())),
                  pseudo_agree=float((pl == g[key("pseudo")]).mean()),
                  pred_agree=float((eng.pred.cpu().numpy() == g[key("pred")]).mean()),
                  rflag_equal=_flags_equal_up_to_marginal(m.classifier_running_proto_exists_flag.cpu().numpy(), g[key("rflag")],
                                                          pl, g[key("pseudo")]),
-                 probs_err=float(np.nanmax(np.abs(eng.probs.cpu().numpy() - g[key("probs")]))))
+                 probs_err=float(np.nanmax(np.abs(eng.probs.cpu().numpy() - g[key("probs")].astype(np.float32)))))
         stats.append(s)
         # 0/0 -> NaN pixels (every existing prototype further than exp() can represent, ttda:1732-1733) are reproduced;
         # which pixels sit exactly on the fp32 underflow edge may differ through bf16 rounding: <= 0.2 % of the pixels
@@ -195,6 +197,18 @@ def test_end_to_end_vs_reference_full_res(diga, gold_full):
     print(stats, mious, gold_full["miou"])
     _check_against_floor(stats, _floor()["full"]["frames"])
     assert np.abs(np.array(mious) - gold_full["miou"]).max() <= 0.1
+
+
+def test_end_to_end_multi_resolution_stream(diga):
+    """BASELINE configs[4]: one stream whose frame size changes (1280x720, 1024x512, 960x540) without resetting the
+    prototypes -- three engines share the one SAM state -- against the reference run of the same stream."""
+    from conftest import load_golden
+    g = load_golden("net_multires.npz")
+    shapes = [tuple(int(v) for v in hw) for hw in g["mr_shapes"]]
+    stats, mious = _run_gold_sequence(diga, g, "mr", 1, 0, 0, len(shapes), shapes=shapes)
+    print(stats, mious, g["mr_miou"])
+    _check_against_floor(stats, None)
+    assert np.abs(np.array(mious) - g["mr_miou"]).max() <= 0.1
 
 
 def test_run_to_run_determinism(weights):
