@@ -211,6 +211,38 @@ def test_end_to_end_multi_resolution_stream(diga):
     assert np.abs(np.array(mious) - g["mr_miou"]).max() <= 0.1
 
 
+def test_config3_batch4_full_resolution(weights):
+    """BASELINE configs[3]: batch 4 at 2048x1024 (M = 4 x 33 153 feature pixels, 11.6 TFLOP per step; the oracle's 5-D
+    prototype temporaries alone would need > 40 GB there), checked through size-independent properties: two runs are
+    bit-identical, the confusion matrix counts every labelled pixel batch-size times (ttda:165), predictions are class
+    ids, the pseudo labels are consistent with the logits, and the SYNTHIA 16-class metric subset is computable."""
+    B, H, W = 4, 1024, 2048
+    outs = []
+    for _ in range(2):
+        eng = Engine(weights, B, H, W, autotune=True)
+        for t in range(2):
+            x, y = synth.synth_frame(40 + t, B, H, W)
+            yd = torch.from_numpy(y).cuda()
+            probs = eng.forward_and_adapt(torch.from_numpy(x).cuda(), yd, CFG)
+            eng.tail(yd)
+        torch.cuda.synchronize()
+        outs.append((probs.cpu().clone(), eng.logits.cpu().clone(), eng.pred.cpu().clone(), eng.hist.cpu().clone(),
+                     eng.run_proto.cpu().clone(), eng.labels[:eng.P].cpu().clone()))
+        valid = sum(int(((synth.synth_frame(40 + t, B, H, W)[1] >= 0) & (synth.synth_frame(40 + t, B, H, W)[1] < 19)).sum()) for t in range(2))
+        del eng
+    for a, b in zip(*outs):
+        assert torch.equal(torch.nan_to_num(a.float(), nan=-1.0), torch.nan_to_num(b.float(), nan=-1.0))
+    probs, logits, pred, hist, run, pl = outs[0]
+    assert probs.shape == (B, 19, 129, 257) and int(hist.sum()) == B * valid
+    assert int(pred.max()) < 19 and torch.isfinite(logits).all() and torch.isfinite(run).all()
+    want = O.pseudo_labels(logits, 0.9).reshape(-1)
+    safe = (logits.softmax(1).max(1)[0].reshape(-1) - 0.9).abs() > 1e-6
+    assert torch.equal(pl.long()[safe], want[safe])
+    met = T.SegmentationMetric(19)
+    met.add_counts(hist.reshape(19, 19))
+    assert 0.0 <= float(met.compute_iou("16")) <= 100.0
+
+
 def test_run_to_run_determinism(weights):
     outs = []
     for _ in range(2):
@@ -226,7 +258,7 @@ def test_run_to_run_determinism(weights):
         assert torch.equal(torch.nan_to_num(a.float(), nan=-1.0), torch.nan_to_num(b.float(), nan=-1.0))
 
 
-@pytest.mark.parametrize("H,W,K", [(129, 257, 3), (512, 1024, 4)])
+@pytest.mark.parametrize("H,W,K", [(129, 257, 3), (512, 1024, 4), (1024, 2048, 2)])
 def test_stream_mode_is_bit_identical_to_batch1_steps(weights, H, W, K):
     """K frames in flight (one trunk pass with per-sample DAM statistics, SAM frame by frame) == K separate batch-1
     steps, bit for bit: probabilities, logits, features, predictions, confusion matrix and the SAM state; two windows
