@@ -6,7 +6,7 @@ full-resolution arg-max/confusion tail) on synthetic 1024x512 frames.
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path: N=1 -> BASELINE.json configs[1] (batch-1 online stream on one MI355X); by default
-6 consecutive frames of the stream are in flight per step (one trunk pass with per-sample DAM statistics, SAM frame by
+7 consecutive frames of the stream are in flight per step (one trunk pass with per-sample DAM statistics, SAM frame by
 frame in order -- bit-identical to one-frame steps, which are measured too and reported as "one_frame_per_step");
 N>1 -> configs[2] (global batch N = one frame per GPU, BN sum/sumsq and prototype sums/counts all-reduced over RCCL;
 weak scaling).  Inputs and labels are resident in HBM before
@@ -45,6 +45,35 @@ def conv_profile(eng, frames, cfg, reps=3):
         out = ms if out is None else out + ms
         meta = [(n, f) for (n, f, _, _) in ev]
     return meta, out / reps
+
+
+def calibrate(dev):
+    """What this box actually sustains, next to the nominal peaks the roofline is priced against: a library bf16 GEMM
+    (hipBLASLt through torch.matmul, 8192^3) and a 1 GiB device copy.  Calibration only: not part of the product path."""
+    out = {}
+    a = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        a @ b
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        a @ b
+    e1.record()
+    torch.cuda.synchronize()
+    out["library_gemm_bf16_8192_tflops"] = round(10 * 2 * 8192 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    out["device_copy_1gib_gbs"] = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)     # read + write bytes
+    out["nominal"] = {"bf16_mfma_tflops": PEAK_BF16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS}
+    return out
 
 
 def cpu_baseline(nframes_timed=2, H=512, W=1024):
@@ -113,11 +142,17 @@ def run_config(args, world, rank, dev, group, weights, fif, steps, warmup):
     for i in range(warmup):
         step(i)
     barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # per-step marks on the launch stream (no sync)
     t0 = time.perf_counter()
+    evs[0].record()
     for i in range(steps):
         step(i)
+        evs[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+    run_config.step_ms = {"median": round(float(np.median(per)), 4), "p10": round(float(np.percentile(per, 10)), 4),
+                          "p90": round(float(np.percentile(per, 90)), 4)}
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -133,7 +168,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--frames-in-flight", type=int, default=6,
+    ap.add_argument("--frames-in-flight", type=int, default=7,
                     help="consecutive batch-1 frames of the stream processed per step (one trunk pass with per-sample DAM "
                          "statistics, SAM frame by frame in stream order; every frame's result is bit-identical to one-frame steps, "
                          "tests/test_gpu_net.py::test_stream_mode_is_bit_identical_to_batch1_steps).  1 = one frame per step.")
@@ -141,6 +176,7 @@ def main():
     ap.add_argument("--no-autotune", action="store_true", help="fixed tile rule instead of timing the tile candidates per conv shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the library-GEMM / device-copy peak check")
     ap.add_argument("--no-latency-mode", action="store_true", help="skip the extra one-frame-per-step measurement")
     ap.add_argument("--dump", default=None, help="write the per-conv timing table to this JSON file")
     args = ap.parse_args()
@@ -174,6 +210,7 @@ def main():
     res = {
         "metric": "adapted frames/sec DeepLabV2-R101 DIGA (DAM+SAM) 1024x512", "value": round(fps, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "step_ms": run_config.step_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": ("BASELINE configs[1]: DIGA TTA stream (DAM+SAM, 19 classes), batch 1, online per-frame prototype/BN-stat "
                                 "updates" + (f"; {fif} consecutive frames in flight per step (per-sample DAM statistics, sequential SAM; "
@@ -210,6 +247,8 @@ def main():
         f1, ms1, e1, _, _ = run_config(args, world, rank, dev, group, weights, 1, max(10, args.steps), min(args.warmup, 10))
         res["one_frame_per_step"] = {"value": round(f1, 2), "unit": "frames/s", "ms_per_step": round(ms1, 4)}
         del e1
+    if rank == 0 and world == 1 and not args.no_calibration:
+        res["calibration"] = calibrate(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:

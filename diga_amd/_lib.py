@@ -44,6 +44,7 @@ SIGNATURES = {
     "diga_bn_apply_nchw_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "diga_bn_relu_maxpool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "diga_head_finish_pseudo_label": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i64, _vp]),
+    "diga_head_tapsum_pseudo_label": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i64, _vp]),
     "diga_nearest_down_labels": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _vp]),
     "diga_proto_pool_work_bytes": (_i64, [_i, _i64, _i, _i]),
     "diga_proto_pool": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),

@@ -44,6 +44,62 @@ __global__ __launch_bounds__(256) void head_finish_pl_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// head as ONE dense GEMM + tap gather (adaptseg:119-121): z[m][t*C + c] = feat[m] . W_t[c] for the 18 taps of the two
+// executed branches is a plain 1x1 igemm (the feature map is read once instead of 18 times); the 3x3 dilated
+// convolutions are then logits[m][c] = bias[c] + sum_t z[m + shift_t][t*C + c] over the taps that land inside the
+// image (zero padding).  Block = 8 pixels x 32 lanes (lane = class): every tap is one contiguous 76-byte read per pixel.
+// The label rule is the one of head_finish_pl_kernel (same arithmetic order).
+// ---------------------------------------------------------------------------------------------
+struct TapList {
+  int n;
+  short dy[DIGA_MAX_TAPS], dx[DIGA_MAX_TAPS];
+};
+
+__global__ __launch_bounds__(256) void head_tapsum_pl_kernel(const float* __restrict__ z, int zstride, const TapList taps,
+                                                             const float* __restrict__ bias, float* __restrict__ logits_out,
+                                                             int32_t* __restrict__ labels, int64_t P, int C, int h, int w, float thr,
+                                                             int64_t lstride) {
+  __shared__ float sl[8][32];
+  const int lane = threadIdx.x & 31, pp = threadIdx.x >> 5;
+  const int64_t p = (int64_t)blockIdx.x * 8 + pp;
+  const int hw = h * w;
+  const bool live = p < P;
+  int64_t b = 0;
+  int pix = 0;
+  if (live) {
+    b = p / hw;
+    pix = (int)(p - b * hw);
+    const int oh = pix / w, ow = pix - oh * w;
+    float acc = lane < C ? bias[lane] : 0.f;
+    if (lane < C) {
+      for (int t = 0; t < taps.n; ++t) {
+        const int ih = oh + taps.dy[t], iw = ow + taps.dx[t];
+        if ((unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w)
+          acc += z[(size_t)(b * hw + ih * w + iw) * zstride + t * C + lane];
+      }
+      logits_out[((size_t)b * C + lane) * hw + pix] = acc;
+    }
+    sl[pp][lane] = acc;
+  }
+  __syncthreads();
+  if (!live || lane != 0) return;
+  float mx = sl[pp][0];
+  int am = 0;
+  for (int c = 1; c < C; ++c) {
+    const float v = sl[pp][c];
+    const bool better = (v > mx) || (v != v && mx == mx);
+    if (better) {
+      mx = v;
+      am = c;
+    }
+  }
+  float sum = 0.f;
+  for (int c = 0; c < C; ++c) sum += expf(sl[pp][c] - mx);
+  const float pmax = 1.0f / sum;
+  labels[b * lstride + pix] = (pmax < thr) ? 255 : am;
+}
+
+// ---------------------------------------------------------------------------------------------
 // nearest down-sampling of the label map (ttda:1695)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
@@ -354,6 +410,26 @@ extern "C" int diga_head_finish_pseudo_label(const float* partials, int splitk, 
   hipLaunchKernelGGL(head_finish_pl_kernel, dim3(cdiv(P, 256)), dim3(256), 0, (hipStream_t)stream, partials, splitk, cpad,
                      bias_sum, logits_in, logits_out, labels, P, C, hw, threshold, label_sample_stride ? label_sample_stride : (int64_t)hw);
   DIGA_CHECK_LAUNCH("diga_head_finish_pseudo_label");
+  return DIGA_OK;
+}
+
+extern "C" int diga_head_tapsum_pseudo_label(const float* z, int zstride, int ntaps, const int16_t* dy_host, const int16_t* dx_host,
+                                             const float* bias_sum, float* logits_out, int32_t* labels, int B, int C, int h, int w,
+                                             float threshold, int64_t label_sample_stride, void* stream) {
+  DIGA_CHECK_ARG(z && dy_host && dx_host && bias_sum && logits_out && labels, "diga_head_tapsum_pseudo_label: NULL pointer");
+  DIGA_CHECK_ARG(B > 0 && h > 0 && w > 0 && C > 0 && C <= 32 && ntaps >= 1 && ntaps <= DIGA_MAX_TAPS && zstride >= ntaps * C,
+                 "diga_head_tapsum_pseudo_label: bad sizes (C <= 32, ntaps <= %d, zstride >= ntaps*C)", DIGA_MAX_TAPS);
+  DIGA_CHECK_ARG(label_sample_stride == 0 || label_sample_stride >= (int64_t)h * w, "diga_head_tapsum_pseudo_label: label stride < h*w");
+  TapList tl;
+  tl.n = ntaps;
+  for (int t = 0; t < DIGA_MAX_TAPS; ++t) {
+    tl.dy[t] = t < ntaps ? dy_host[t] : 0;
+    tl.dx[t] = t < ntaps ? dx_host[t] : 0;
+  }
+  const int64_t P = (int64_t)B * h * w;
+  hipLaunchKernelGGL(head_tapsum_pl_kernel, dim3(cdiv(P, 8)), dim3(256), 0, (hipStream_t)stream, z, zstride, tl, bias_sum, logits_out,
+                     labels, P, C, h, w, threshold, label_sample_stride ? label_sample_stride : (int64_t)h * w);
+  DIGA_CHECK_LAUNCH("diga_head_tapsum_pseudo_label");
   return DIGA_OK;
 }
 

@@ -120,11 +120,16 @@ class NetWeights:
         self.bn_channels = off
         # heads: the two executed branches (dil 6 + dil 12, adaptseg.py:119-122) fused into one 18-tap conv,
         # Cout padded 19 -> 32.  layer6 = main head (on layer4), layer5 = aux head (on layer3, only for net(x)).
-        self.head_cpad = 32
+        # As a GEMM: z[m][t*C + c] = feat[m] . W_t[c] for the 18 taps t -> one 1x1 conv with Cout = 18*C (padded to a
+        # multiple of 128), then a tap gather (diga_head_tapsum_pseudo_label): the feature map is read once, not 18 times.
+        self.head_cout = 18 * num_classes
+        self.head_cpad = -(-self.head_cout // 128) * 128
 
         def pack_head(prefix):
             w0, w1 = dev(sd[prefix + ".conv2d_list.0.weight"]), dev(sd[prefix + ".conv2d_list.1.weight"])
-            hw = pack_taps([w0, w1], self.head_cpad)
+            # rows (tap, class): [br][kh][kw][c][ci]
+            rows = torch.cat([w.permute(2, 3, 0, 1).reshape(9 * num_classes, w.shape[1]) for w in (w0, w1)], 0)
+            hw = pack_conv_weight(rows[:, :, None, None], self.head_cpad)
             return hw, (dev(sd[prefix + ".conv2d_list.0.bias"]) + dev(sd[prefix + ".conv2d_list.1.bias"])).contiguous()
 
         self.head_w, self.head_bias = pack_head("layer6")
@@ -197,7 +202,9 @@ class Engine:
         self.slab = buf(max(self.stem_units * 2 * 64, units(self.h2 * self.w2) * 2 * 256, units(self.h3 * self.w3) * 2 * 2048), f32)
         self.sums = buf(4 * 2048 * self.na, torch.float64)
         # head / SAM
-        self.head_part = buf(head_splitk * self.P * weights.head_cpad, f32)
+        self.head_part = buf(self.P * weights.head_cpad, f32)        # z of the head GEMM
+        self.head_dy = (C.c_int16 * 18)(*[(t % 9 // 3 - 1) * HEAD_DILS[t // 9] for t in range(18)])
+        self.head_dx = (C.c_int16 * 18)(*[(t % 3 - 1) * HEAD_DILS[t // 9] for t in range(18)])
         self.logits = torch.empty(B, self.C, self.h, self.wd, dtype=f32, device=dev)
         # labels: batch mode [2][P] = [pseudo | ground truth] over the batch; stream mode [B][2][hw] (per frame)
         self.labels = buf(2 * self.P, i32)
@@ -311,7 +318,8 @@ class Engine:
             for r in range(reps + 1):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                call("diga_conv_igemm_bf16", C.byref(d), _p(x), _p(wgt), _p(out), _p(self.slab), _p(bn.running_mean), _stream())
+                call("diga_conv_igemm_bf16", C.byref(d), _p(x), _p(wgt), _p(out), _p(self.slab) if bn is not None else None,
+                     _p(bn.running_mean) if bn is not None else None, _stream())
                 e1.record()
                 evs.append((e0, e1))
             torch.cuda.synchronize()
@@ -402,20 +410,23 @@ class Engine:
 
     def _head(self, feat, cin, hw, hbias, logits, labels, lstride):
         d = ConvDesc()
-        d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = self.B, self.h, self.wd, cin, self.h, self.wd, self.C
-        d.stride, d.ntaps = 1, 18
-        for br, dil in enumerate(HEAD_DILS):
-            for t in range(9):
-                d.dy[br * 9 + t], d.dx[br * 9 + t] = (t // 3 - 1) * dil, (t % 3 - 1) * dil
+        d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = self.B, self.h, self.wd, cin, self.h, self.wd, self.w.head_cout
+        d.stride, d.ntaps = 1, 1
         d.cout_pad = self.w.head_cpad
-        d.splitk, d.out_f32, d.tile = self.head_splitk, 1, 0
+        d.splitk, d.out_f32, d.tile = 1, 1, self.conv_tile
+        if self.autotune:
+            key = ("head", cin)
+            if key not in self.tile_cache and not torch.cuda.is_current_stream_capturing():
+                self.tile_cache[key] = self._tune(d, feat, hw, self.head_part, None)
+            d.tile = self.tile_cache.get(key, 0)
+        flops = 2 * self.P * self.C * cin * 18
         ev = self._ev_start()
         call("diga_conv_igemm_bf16", C.byref(d), _p(feat), _p(hw), _p(self.head_part), None, None, _stream())
-        self._ev_end(ev, "head", 2 * self.P * self.C * cin * 18)
-        self.conv_flops += 2 * self.P * self.C * cin * 18
-        # split-K partials + bias -> logits (NCHW fp32) and the confidence-thresholded pseudo labels (ttda:1662-1676)
-        call("diga_head_finish_pseudo_label", _p(self.head_part), self.head_splitk, self.w.head_cpad, _p(hbias), None,
-             _p(logits), _p(labels), self.B, self.C, self.hw, self.threshold, lstride, _stream())
+        self._ev_end(ev, "head", flops)
+        self.conv_flops += flops
+        # tap gather + bias -> logits (NCHW fp32) and the confidence-thresholded pseudo labels (ttda:1662-1676)
+        call("diga_head_tapsum_pseudo_label", _p(self.head_part), self.w.head_cpad, 18, self.head_dy, self.head_dx, _p(hbias),
+             _p(logits), _p(labels), self.B, self.C, self.h, self.wd, self.threshold, lstride, _stream())
 
     # ------------------------------------------------------------------ SAM + fusion
     def sam_fuse(self, y: torch.Tensor, cfg):

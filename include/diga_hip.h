@@ -146,6 +146,16 @@ int diga_head_finish_pseudo_label(const float* partials, int splitk, int cpad, c
                                   int B, int C, int hw, float threshold, int64_t label_sample_stride,
                                   void* stream);
 
+/* The same head as ONE dense GEMM + tap gather: z = fp32 [B*h*w][zstride] with z[m][t*C + c] = feat[m] . W_t[c]
+ * (a 1x1 diga_conv_igemm_bf16 with Cout = ntaps*C, out_f32, that reads the feature map once instead of ntaps
+ * times); logits[m][c] = bias_sum[c] + sum over the taps t whose pixel m + (dy[t], dx[t]) lies inside the image of
+ * z[that pixel][t*C + c] (adaptseg:119-121, zero padding); then the pseudo-label rule above.
+ * dy_host / dx_host: HOST arrays of ntaps tap offsets in feature pixels. */
+int diga_head_tapsum_pseudo_label(const float* z, int zstride, int ntaps, const int16_t* dy_host,
+                                  const int16_t* dx_host, const float* bias_sum, float* logits_out,
+                                  int32_t* labels, int B, int C, int h, int w, float threshold,
+                                  int64_t label_sample_stride, void* stream);
+
 /* F.interpolate(y.float(), size=(h,w), mode='nearest').long() (ttda:1695): src = floor(dst*in/out)
  * computed as the reference does (fp32 scale).  y: int64 (y_is_i64) or int32 [B,H,W] -> int32 [B,h,w];
  * out_sample_stride as label_sample_stride above (0 = dense). */

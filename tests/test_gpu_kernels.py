@@ -173,6 +173,41 @@ def test_head_conv_and_pseudo_labels(B, h, w, splitk):
     assert (~safe).sum() <= 2
 
 
+@pytest.mark.parametrize("B,h,w", [(1, 9, 17), (2, 13, 21), (1, 33, 65)])
+def test_head_as_gemm_plus_tap_gather(B, h, w):
+    """The product path's head: one dense 1x1 igemm (Cout = 18 taps x 19 classes) + diga_head_tapsum_pseudo_label."""
+    g = torch.Generator().manual_seed(17 + h)
+    CH, NC = 2048, 19
+    feat = bf16_round(torch.randn(B, CH, h, w, generator=g).relu() * 0.3)
+    w0 = bf16_round(torch.randn(NC, CH, 3, 3, generator=g) * 0.05)
+    w1 = bf16_round(torch.randn(NC, CH, 3, 3, generator=g) * 0.05)
+    b0, b1 = torch.randn(NC, generator=g) * 0.5, torch.randn(NC, generator=g) * 0.5
+    ref = O.head_logits({"layer6.conv2d_list.0.weight": w0, "layer6.conv2d_list.0.bias": b0, "layer6.conv2d_list.1.weight": w1,
+                         "layer6.conv2d_list.1.bias": b1}, feat)
+    rows = torch.cat([x.permute(2, 3, 0, 1).reshape(9 * NC, CH) for x in (w0, w1)], 0)
+    cpad = 384
+    wp = pack_conv_weight(rows[:, :, None, None], cpad).to(DEV)
+    d = conv_desc(B, h, w, CH, 18 * NC, cout_pad=cpad)
+    d.out_f32 = 1
+    Pn = B * h * w
+    z = torch.full((Pn * cpad,), float("nan"), dtype=torch.float32, device=DEV)
+    fd = to_nhwc_bf16(feat)
+    call("diga_conv_igemm_bf16", C.byref(d), P(fd), P(wp), P(z), None, None, stream())
+    dy = (C.c_int16 * 18)(*[(t % 9 // 3 - 1) * (6, 12)[t // 9] for t in range(18)])
+    dx = (C.c_int16 * 18)(*[(t % 3 - 1) * (6, 12)[t // 9] for t in range(18)])
+    logits = torch.empty(B, NC, h, w, dtype=torch.float32, device=DEV)
+    labels = torch.empty(Pn, dtype=torch.int32, device=DEV)
+    bias = (b0 + b1).to(DEV)
+    call("diga_head_tapsum_pseudo_label", P(z), cpad, 18, dy, dx, P(bias), P(logits), P(labels), B, NC, h, w, float(np.float32(0.9)), 0,
+         stream())
+    torch.cuda.synchronize()
+    assert rel_err(logits.cpu(), ref) < 1e-4
+    lg = logits.cpu()
+    want = O.pseudo_labels(lg, 0.9).reshape(-1).numpy()
+    safe = np.abs(lg.softmax(1).max(1)[0].reshape(-1).numpy() - 0.9) > 1e-6
+    assert np.array_equal(labels.cpu().numpy()[safe], want[safe]) and (~safe).sum() <= 2
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 65, 129), (2, 47, 35), (1, 129, 257)])
 def test_stem_bn_maxpool(B, H, W):
     g = torch.Generator().manual_seed(H)
