@@ -174,12 +174,12 @@ __global__ __launch_bounds__(256) void proto_pool_kernel(const unsigned short* _
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
     int q = beg;
-    for (; q + 4 <= end; q += 4) {
-      u32x4 r[4];
+    for (; q + 8 <= end; q += 8) {        // 8 independent 16-byte row reads in flight per lane
+      u32x4 r[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const u32x4*>(feat + (size_t)list[q + u] * CH + ch0);
+      for (int u = 0; u < 8; ++u) r[u] = *reinterpret_cast<const u32x4*>(feat + (size_t)list[q + u] * CH + ch0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         float f[8];
         unpack_bf16x8(r[u], f);
 #pragma unroll
@@ -456,8 +456,10 @@ struct PoolPlan {
 };
 PoolPlan pool_plan(int nsets, int64_t P, int C, int CH) {
   PoolPlan pp;
-  pp.CS = (int)((P + 63) / 64);
-  if (pp.CS < 64) pp.CS = 64;
+  // chunk = list positions one block sums: ~P/256 so that the dominant classes alone spread over the whole chip
+  // (a chunk is a latency-bound chain of row reads; the partial buffer costs nsets*C*JC*CH floats)
+  pp.CS = (int)((P + 255) / 256);
+  if (pp.CS < 32) pp.CS = 32;
   pp.JC = (int)((P + pp.CS - 1) / pp.CS);
   pp.idx_bytes = (((int64_t)nsets * C * P * 4) + 255) / 256 * 256;
   pp.partial_bytes = (int64_t)nsets * C * pp.JC * CH * 4;

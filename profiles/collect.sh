@@ -9,9 +9,9 @@ O=gpurun_out/prof_r1c
 mkdir -p $O
 FIF=${FIF:-6}
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- \
-  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency-mode --frames-in-flight $FIF > $O/trace.log 2>&1
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency-mode --no-calibration --frames-in-flight $FIF > $O/trace.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- \
-  python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency-mode --no-roofline --no-graph --frames-in-flight $FIF > $O/fetch.log 2>&1
+  python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency-mode --no-roofline --no-calibration --no-graph --frames-in-flight $FIF > $O/fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- \
-  python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency-mode --no-roofline --no-graph --frames-in-flight $FIF > $O/write.log 2>&1
+  python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency-mode --no-roofline --no-calibration --no-graph --frames-in-flight $FIF > $O/write.log 2>&1
 ls $O/*
