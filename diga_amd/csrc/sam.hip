@@ -296,11 +296,12 @@ __global__ __launch_bounds__(128) void proto_dist_kernel(const unsigned short* _
   const int tid = threadIdx.x, pg = tid & 15, sg = tid >> 4;
   const int64_t p0 = (int64_t)blockIdx.x * PCF_PIX;
   const int chb = blockIdx.y * ch_per_split;
-  float acc[4][5];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc[2][5];                       // [pixel pair][prototype]: packed fp32 (v_pk_add_f32 / v_pk_fma_f32)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int k = 0; k < 5; ++k) acc[i][k] = 0.f;
+    for (int k = 0; k < 5; ++k) acc[i][k] = f32x2{0.f, 0.f};
   for (int ch0 = chb; ch0 < chb + ch_per_split; ch0 += 64) {
     __syncthreads();
 #pragma unroll
@@ -328,14 +329,14 @@ __global__ __launch_bounds__(128) void proto_dist_kernel(const unsigned short* _
       const f32x4 f = *reinterpret_cast<const f32x4*>(&sf[ch][pg * 4]);
       const f32x4 q = *reinterpret_cast<const f32x4*>(&spr[ch][sg][0]);
       const float q4 = spr[ch][sg][4];
+      const f32x2 f01 = f32x2{f[0], f[1]}, f23 = f32x2{f[2], f[3]};
+      const float qq[5] = {q[0], q[1], q[2], q[3], q4};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float d;
-        d = q[0] - f[i]; acc[i][0] = fmaf(d, d, acc[i][0]);
-        d = q[1] - f[i]; acc[i][1] = fmaf(d, d, acc[i][1]);
-        d = q[2] - f[i]; acc[i][2] = fmaf(d, d, acc[i][2]);
-        d = q[3] - f[i]; acc[i][3] = fmaf(d, d, acc[i][3]);
-        d = q4 - f[i];   acc[i][4] = fmaf(d, d, acc[i][4]);
+      for (int k = 0; k < 5; ++k) {
+        const f32x2 qk = f32x2{qq[k], qq[k]};
+        const f32x2 d0 = qk - f01, d1 = qk - f23;
+        acc[0][k] = __builtin_elementwise_fma(d0, d0, acc[0][k]);
+        acc[1][k] = __builtin_elementwise_fma(d1, d1, acc[1][k]);
       }
     }
   }
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(128) void proto_dist_kernel(const unsigned short* _
     const int64_t p = p0 + pg * 4 + i;
     if (p < P) {
 #pragma unroll
-      for (int k = 0; k < 5; ++k) w[p * PCF_SLOTS + sg * 5 + k] = acc[i][k];
+      for (int k = 0; k < 5; ++k) w[p * PCF_SLOTS + sg * 5 + k] = acc[i >> 1][k][i & 1];
     }
   }
 }
