@@ -24,6 +24,7 @@
 // cross-half shuffle), written to a slab that diga_bn_finalize sums in fixed order (deterministic, no atomics,
 // independent of the tile shape);  (2) the raw output is staged through LDS and stored as 16-byte NHWC rows.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -47,7 +48,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int S, int BK, bool OUT_F32, bool STATS>
+template <int BM, int BN, int WM, int WN, int S, int BK, bool ILV, bool OUT_F32, bool STATS>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKParams p) {
   constexpr int NW = WM * WN, NTHR = 64 * NW;        // 4 or 8 waves
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -129,7 +130,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     is_tap = q - is_chunk * p.ntaps;
   }
   int is_dd = p.dydx[is_tap];
-  auto issue_next = [&](int stage) {
+  // One K step's loads are LPT pieces (A pieces, then B pieces).  issue_pieces<lo, hi> issues pieces [lo, hi) of the next
+  // K step; advance_next() moves on to the following step.  ILV kernels spread the pieces over the MFMA groups of the
+  // running step (an LDS-DMA piece costs the issuing wave ~100 cycles: issued in one burst right after the barrier,
+  // both waves of a SIMD burst together and the MFMA pipe idles).
+  auto issue_pieces = [&](int stage, auto lo_c, auto hi_c) {
+    constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
     const int kk = is_ks * BK;
     const int c0 = is_chunk * 64 + (BK == 64 ? 0 : (is_ks & 1) * 32);
     const int dy = is_dd >> 16, dx = (int)(short)(is_dd & 0xffff);
@@ -138,13 +144,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     unsigned char* const dB = dA + A_BYTES;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
+      if (i < lo || i >= hi) continue;
       const bool ok = (unsigned)(ih0[i] + dy) < (unsigned)p.H && (unsigned)(iw0[i] + dx) < (unsigned)p.W;
       const unsigned short* src = ok ? in + (pixoff[i] + tapoff) : zero;
       __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(dA + i * NW * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < B_CH; ++j)
+    for (int j = 0; j < B_CH; ++j) {
+      if (A_CH + j < lo || A_CH + j >= hi) continue;
       __builtin_amdgcn_global_load_lds((gbl_ptr)(wgt + (wrow_off[j] + kk)), (lds_ptr)(dB + j * NW * 1024), 16, 0, 0);
+    }
+  };
+  auto advance_next = [&]() {
     ++is_ks;
     if (BK == 64 || !(is_ks & 1)) {
       if (++is_tap == p.ntaps) {
@@ -153,6 +164,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
       }
       is_dd = p.dydx[is_tap];
     }
+  };
+  auto issue_next = [&](int stage) {
+    issue_pieces(stage, std::integral_constant<int, 0>{}, std::integral_constant<int, LPT>{});
+    advance_next();
   };
 
   f32x16 acc[MT][NT];
@@ -179,23 +194,34 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     else if (younger == 1) wait_vmcnt<(D >= 2 ? 1 : 0) * LPT>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();       // every wave's part of tile t is in LDS; everyone is done reading tile t-1
-    if (t + D < nt) issue_next(fill);   // K step t+D refills the buffer tile t-1 was read from
+    const bool more = t + D < nt;       // K step t+D refills the buffer tile t-1 was read from
+    if (!ILV && more) issue_next(fill);
     const unsigned char* bA = smem + stage * STAGE_BYTES + fa_row;
     const unsigned char* bB = smem + stage * STAGE_BYTES + fb_row;
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
+    constexpr int KS = BK / 16;
+    auto ksub = [&](auto s_c) {
+      constexpr int s = decltype(s_c)::value;
       const int coff = ((2 * s + hh) ^ fr_swz) << 4;
       bf16x8 fa[MT], fb[NT];
 #pragma unroll
       for (int a = 0; a < MT; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(bA + a * 32 * ROWB + coff);
 #pragma unroll
       for (int b = 0; b < NT; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(bB + b * 32 * ROWB + coff);
+      if (ILV && more)                  // this group's share of the next K step's loads, in the shadow of the MFMAs below
+        issue_pieces(fill, std::integral_constant<int, s * LPT / KS>{}, std::integral_constant<int, (s + 1) * LPT / KS>{});
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    };
+    ksub(std::integral_constant<int, 0>{});
+    ksub(std::integral_constant<int, 1>{});
+    if constexpr (KS == 4) {
+      ksub(std::integral_constant<int, 2>{});
+      ksub(std::integral_constant<int, 3>{});
     }
+    if (ILV && more) advance_next();
     stage = stage + 1 == S ? 0 : stage + 1;
     fill = fill + 1 == S ? 0 : fill + 1;
   }
@@ -285,6 +311,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
 
 struct TileCfg {
   int id, BM, BN, S, BK = 64;
+  bool ilv = false;
 };
 // id = shape + 10*(4 - ring depth).  shape 1: 128x128, 2: 128x64, 3: 64x64, 4: 64x128, 5: 128x32 (head); 8-wave blocks:
 // 6: 256x128, 7: 128x256, 8: 256x256 (ring depth 2 only).  ids 31..38: the same shapes with 32-channel K steps and a 4-deep
@@ -295,7 +322,13 @@ const TileCfg kTiles[] = {{1, 128, 128, 4}, {11, 128, 128, 3}, {21, 128, 128, 2}
                           {5, 128, 32, 4},  {15, 128, 32, 3},  {25, 128, 32, 2},  {16, 256, 128, 3}, {26, 256, 128, 2}, {17, 128, 256, 3},
                           {27, 128, 256, 2}, {28, 256, 256, 2},
                           {31, 128, 128, 4, 32}, {32, 128, 64, 4, 32}, {33, 64, 64, 4, 32}, {34, 64, 128, 4, 32}, {36, 256, 128, 4, 32},
-                          {37, 128, 256, 4, 32}, {38, 256, 256, 4, 32}};
+                          {37, 128, 256, 4, 32}, {38, 256, 256, 4, 32},
+                          // ids 46..48 / 56..58: ring depth 2 (64-channel steps) / 4 (32-channel steps) with the next step's
+                          // loads interleaved with the MFMA groups
+                          // loads interleaved with the MFMA groups (pays for the 8-wave tiles only; 4-wave 256x256 tiles -- one
+                          // wave per SIMD, 256 accumulator registers -- were measured 15-25 % slower and are not built)
+                          {46, 256, 128, 2, 64, true}, {47, 128, 256, 2, 64, true}, {48, 256, 256, 2, 64, true},
+                          {56, 256, 128, 4, 32, true}, {57, 128, 256, 4, 32, true}, {58, 256, 256, 4, 32, true}};
 
 const TileCfg* find_tile(int id) {
   for (const auto& t : kTiles)
@@ -313,7 +346,7 @@ int auto_tile(const diga_conv_desc* d) {
   return 23;                                                                      // 64x64
 }
 
-template <int BM, int BN, int WM, int WN, int S, int BK = 64>
+template <int BM, int BN, int WM, int WN, int S, int BK = 64, bool ILV = false>
 int launch_cfg(const ConvKParams& p, int splitk, bool out_f32, bool stats, hipStream_t st) {
   constexpr int main_bytes = S * (BM + BN) * BK * 2;
   constexpr int epi_bytes = BM * BN * 2;
@@ -321,17 +354,17 @@ int launch_cfg(const ConvKParams& p, int splitk, bool out_f32, bool stats, hipSt
   dim3 grid(p.mtiles * p.ntiles_n, splitk), block(64 * WM * WN);
   static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, BK, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, BK, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, BK, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   if (out_f32 && !stats)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, BK, true, false>), grid, block, smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, true, false>), grid, block, smem, st, p);
   else if (!out_f32 && stats)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, BK, false, true>), grid, block, smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, false, true>), grid, block, smem, st, p);
   else if (!out_f32 && !stats)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, BK, false, false>), grid, block, smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, false, false>), grid, block, smem, st, p);
   else {
     diga_set_error("diga_conv_igemm_bf16: statistics with fp32 split-K output are not supported");
     return DIGA_EINVAL;
@@ -422,6 +455,12 @@ extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, con
     case 36: e = launch_cfg<256, 128, 4, 2, 4, 32>(p, d->splitk, f32, stats, st); break;
     case 37: e = launch_cfg<128, 256, 2, 4, 4, 32>(p, d->splitk, f32, stats, st); break;
     case 38: e = launch_cfg<256, 256, 2, 4, 4, 32>(p, d->splitk, f32, stats, st); break;
+    case 46: e = launch_cfg<256, 128, 4, 2, 2, 64, true>(p, d->splitk, f32, stats, st); break;
+    case 47: e = launch_cfg<128, 256, 2, 4, 2, 64, true>(p, d->splitk, f32, stats, st); break;
+    case 48: e = launch_cfg<256, 256, 2, 4, 2, 64, true>(p, d->splitk, f32, stats, st); break;
+    case 56: e = launch_cfg<256, 128, 4, 2, 4, 32, true>(p, d->splitk, f32, stats, st); break;
+    case 57: e = launch_cfg<128, 256, 2, 4, 4, 32, true>(p, d->splitk, f32, stats, st); break;
+    case 58: e = launch_cfg<256, 256, 2, 4, 4, 32, true>(p, d->splitk, f32, stats, st); break;
   }
 #undef DIGA_TILE_CASES
   if (e) return e;
