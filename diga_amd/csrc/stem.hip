@@ -4,21 +4,25 @@
 //
 // Cin = 3 makes this a 147-deep dot product per output: too thin for the generic 64-channel gather,
 // and only 0.3 % of the frame's FLOPs, so it runs on the fp32 VALU from LDS: a block owns a strip of
-// ROWS output rows x 64 output columns x 64 channels, keeps the 37 KB weight matrix in LDS for the
-// whole strip and re-stages the 7 x 133 x 3 input patch per output row.
+// ROWS output rows x 64 output columns x 64 channels, with the 37 KB weight matrix and the strip's
+// 13 x 133 x 3 input patch in LDS.
 #include "common.h"
 
 namespace {
 
-constexpr int ROWS = 4;        // output rows per block
+constexpr int ROWS = 4;        // output rows per block, all four accumulated in registers
+constexpr int PR = 2 * (ROWS - 1) + 7;   // input rows the strip needs (13)
 constexpr int PW = 134;        // patch row pitch (133 used)
 
+// A thread owns output column `lane` of the strip's ROWS rows x 16 channels (64 accumulators): every weight vector
+// read from LDS (4 x b128, broadcast) feeds ROWS x 16 FMAs, every input value 16.  The accumulation order per output
+// is (c, kh, kw), the order of the reference's 147-deep dot product layout [c][kh][kw].
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                    unsigned short* __restrict__ out, float* __restrict__ slab,
                                                    const float* __restrict__ shift, int H, int W, int Ho, int Wo,
                                                    int tiles_w, int tiles_h) {
   __shared__ __attribute__((aligned(16))) float sw[147 * 64];   // [k][cout]
-  __shared__ float sp[3 * 7 * PW];
+  __shared__ float sp[3 * PR * PW];                             // [c][input row][col]
   __shared__ float sred[4][2][16];
   const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6;
   int b = blockIdx.x;
@@ -31,57 +35,65 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     const int co = e & 63, k = e >> 6;
     sw[e] = wgt[co * 147 + k];
   }
+  const float* xin = x + (size_t)n * 3 * H * W;
+  for (int e = tid; e < 3 * PR * 133; e += 256) {
+    const int j = e % 133, cr = e / 133;
+    const int r = cr % PR, c = cr / PR;
+    const int ih = oh0 * 2 - 3 + r, iw = ow0 * 2 - 3 + j;
+    float v = 0.f;
+    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = xin[((size_t)c * H + ih) * W + iw];
+    sp[cr * PW + j] = v;
+  }
+  __syncthreads();
+
+  float acc[ROWS][16];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+  for (int c = 0; c < 3; ++c)
+    for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) {
+        const f32x4* wv = reinterpret_cast<const f32x4*>(&sw[((c * 7 + kh) * 7 + kw) * 64 + cg * 16]);
+        const f32x4 w0 = wv[0], w1 = wv[1], w2 = wv[2], w3 = wv[3];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          const float xv = sp[(c * PR + 2 * r + kh) * PW + 2 * lane + kw];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[r][i] = fmaf(xv, w0[i], acc[r][i]);
+            acc[r][4 + i] = fmaf(xv, w1[i], acc[r][4 + i]);
+            acc[r][8 + i] = fmaf(xv, w2[i], acc[r][8 + i]);
+            acc[r][12 + i] = fmaf(xv, w3[i], acc[r][12 + i]);
+          }
+        }
+      }
+    }
+
   float kshift[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) kshift[i] = shift[cg * 16 + i];
   float s1[16], s2[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) s1[i] = s2[i] = 0.f;
-
-  const float* xin = x + (size_t)n * 3 * H * W;
+  const int ow = ow0 + lane;
+#pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     const int oh = oh0 + r;
-    if (oh >= Ho) break;                                   // uniform over the block
-    __syncthreads();
-    for (int e = tid; e < 3 * 7 * 133; e += 256) {
-      const int j = e % 133, ck = e / 133;
-      const int kh = ck % 7, c = ck / 7;
-      const int ih = oh * 2 - 3 + kh, iw = ow0 * 2 - 3 + j;
-      float v = 0.f;
-      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = xin[((size_t)c * H + ih) * W + iw];
-      sp[ck * PW + j] = v;
-    }
-    __syncthreads();
-    float acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int ck = 0; ck < 21; ++ck) {
-#pragma unroll
-      for (int kw = 0; kw < 7; ++kw) {
-        const float xv = sp[ck * PW + 2 * lane + kw];
-        const f32x4* wv = reinterpret_cast<const f32x4*>(&sw[(ck * 7 + kw) * 64 + cg * 16]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 w4 = wv[q];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[q * 4 + i] = fmaf(xv, w4[i], acc[q * 4 + i]);
-        }
-      }
-    }
-    const int ow = ow0 + lane;
-    if (ow < Wo) {
+    if (oh < Ho && ow < Wo) {
       u32x4 lo, hi;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        lo[i] = pack_bf16x2(acc[2 * i], acc[2 * i + 1]);
-        hi[i] = pack_bf16x2(acc[8 + 2 * i], acc[8 + 2 * i + 1]);
+        lo[i] = pack_bf16x2(acc[r][2 * i], acc[r][2 * i + 1]);
+        hi[i] = pack_bf16x2(acc[r][8 + 2 * i], acc[r][8 + 2 * i + 1]);
       }
       u32x4* o = reinterpret_cast<u32x4*>(out + (((size_t)n * Ho + oh) * Wo + ow) * 64 + cg * 16);
       o[0] = lo;
       o[1] = hi;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float d = acc[i] - kshift[i];
+        const float d = acc[r][i] - kshift[i];
         s1[i] += d;
         s2[i] = fmaf(d, d, s2[i]);
       }
