@@ -302,28 +302,38 @@ __global__ __launch_bounds__(128) void proto_dist_kernel(const unsigned short* _
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int k = 0; k < 5; ++k) acc[i][k] = f32x2{0.f, 0.f};
-  for (int ch0 = chb; ch0 < chb + ch_per_split; ch0 += 64) {
-    __syncthreads();
+  // the next chunk's global data (4 feature octets + 8 prototype float4 per thread) is fetched into registers while
+  // the current chunk is being reduced, so its latency is off the critical path
+  u32x4 fr[4];
+  f32x4 pr[8];
+  auto fetch = [&](int ch0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {            // feature tile: 64 px x 8 octets, 4 per thread; 8 lanes read one 128-B row
       const int id = tid + 128 * j, r = id >> 3, o = id & 7;
-      float f[8];
-      if (p0 + r < P) {
-        unpack_bf16x8(*reinterpret_cast<const u32x4*>(feat + (size_t)(p0 + r) * CH + ch0 + o * 8), f);
-      } else {
+      fr[j] = p0 + r < P ? *reinterpret_cast<const u32x4*>(feat + (size_t)(p0 + r) * CH + ch0 + o * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    const f32x4* src = reinterpret_cast<const f32x4*>(protoT + (size_t)ch0 * 64);   // prototype image: straight 16 KB copy
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = 0.f;
-      }
+    for (int j = 0; j < 8; ++j) pr[j] = src[tid + 128 * j];
+  };
+  fetch(chb);
+  for (int ch0 = chb; ch0 < chb + ch_per_split; ch0 += 64) {
+    __syncthreads();                           // everyone is done reading the previous chunk's LDS image
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int id = tid + 128 * j, r = id >> 3, o = id & 7;
+      float f[8];
+      unpack_bf16x8(fr[j], f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) sf[o * 8 + i][r] = f[i];
     }
-    {                                          // prototype image of these 64 channels: straight 16 KB copy
-      const f32x4* src = reinterpret_cast<const f32x4*>(protoT + (size_t)ch0 * 64);
+    {
       f32x4* dst = reinterpret_cast<f32x4*>(&spr[0][0][0]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dst[tid + 128 * j] = src[tid + 128 * j];
+      for (int j = 0; j < 8; ++j) dst[tid + 128 * j] = pr[j];
     }
     __syncthreads();
+    if (ch0 + 64 < chb + ch_per_split) fetch(ch0 + 64);
 #pragma unroll 4
     for (int ch = 0; ch < 64; ++ch) {
       const f32x4 f = *reinterpret_cast<const f32x4*>(&sf[ch][pg * 4]);
