@@ -30,7 +30,18 @@ PEAK_HBM_GBS = 8000.0          # HBM3E spec peak, same guide
 
 
 def conv_profile(eng, frames, cfg, reps=3):
-    """Per-launch HIP-event timing (on the launch stream) of every igemm conv of a frame, eager mode."""
+    """Per-launch HIP-event timing (on the launch stream) of every igemm conv of a step, eager mode.  An event pair
+    around nothing still measures a few microseconds (the second event's own latency): that empty-pair time, taken as
+    the median of 64 pairs on the same stream, is subtracted from every launch so that the durations are comparable
+    with rocprofv3's kernel begin/end times (profiles/r1c_kernel_roofline.md)."""
+    pairs = []
+    for _ in range(64):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    empty_ms = float(np.median([a.elapsed_time(b) for a, b in pairs]))
     out = None
     for r in range(reps + 1):
         eng.conv_events = []
@@ -41,9 +52,10 @@ def conv_profile(eng, frames, cfg, reps=3):
         eng.conv_events = None
         if r == 0:
             continue           # warm-up
-        ms = np.array([s.elapsed_time(e) for (_, _, s, e) in ev])
+        ms = np.maximum(np.array([s.elapsed_time(e) for (_, _, s, e) in ev]) - empty_ms, 0.0)
         out = ms if out is None else out + ms
         meta = [(n, f) for (n, f, _, _) in ev]
+    conv_profile.empty_pair_us = round(empty_ms * 1e3, 2)
     return meta, out / reps
 
 
@@ -236,7 +248,8 @@ def main():
         res["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (all igemm launches of one step)",
                            "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                            "traffic": traffic, "launches_per_step": len(meta), "avg_launch_us": round(total_ms * 1e3 / len(meta), 2),
-                           "kernel_ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(igemm_flops / 1e9, 3)}
+                           "kernel_ms_per_step": round(total_ms, 4), "algorithmic_gflop_per_step": round(igemm_flops / 1e9, 3),
+                           "event_pair_overhead_us_subtracted": conv_profile.empty_pair_us}
         if args.dump:
             with open(args.dump, "w") as f:
                 json.dump([dict(name=n, gflop=fl / 1e9, us=float(m) * 1e3, tflops=fl / (float(m) * 1e-3) / 1e12)
