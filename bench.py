@@ -88,7 +88,7 @@ def calibrate(dev):
     return out
 
 
-def cpu_baseline(nframes_timed=2, H=512, W=1024):
+def cpu_baseline(nframes_timed=10, H=512, W=1024):
     """The CPU oracle (a restatement of the reference's PyTorch CPU path; oracle/diga_oracle.py) on the host
     cores of this box: 1 warm-up + nframes_timed frames of forward_and_adapt + upsample + metric."""
     from diga_amd import synth

@@ -49,7 +49,7 @@ def diga(synth_params_np):
     return m
 
 
-@pytest.mark.parametrize("B,H,W", [(1, 65, 129), (2, 65, 129), (1, 129, 257)])
+@pytest.mark.parametrize("B,H,W", [(1, 65, 129), (2, 65, 129), (1, 129, 257), (3, 33, 41)])
 def test_stage_isolated_whole_net(weights, synth_params_np, B, H, W):
     pt = O.to_torch(synth_params_np)
     eng = Engine(weights, B, H, W)
