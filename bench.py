@@ -6,7 +6,7 @@ full-resolution arg-max/confusion tail) on synthetic 1024x512 frames.
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path: N=1 -> BASELINE.json configs[1] (batch-1 online stream on one MI355X); by default
-7 consecutive frames of the stream are in flight per step (one trunk pass with per-sample DAM statistics, SAM frame by
+15 consecutive frames of the stream are in flight per step (one trunk pass with per-sample DAM statistics, SAM frame by
 frame in order -- bit-identical to one-frame steps, which are measured too and reported as "one_frame_per_step");
 N>1 -> configs[2] (global batch N = one frame per GPU, BN sum/sumsq and prototype sums/counts all-reduced over RCCL;
 weak scaling).  Inputs and labels are resident in HBM before
@@ -180,7 +180,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--frames-in-flight", type=int, default=7,
+    ap.add_argument("--frames-in-flight", type=int, default=15,
                     help="consecutive batch-1 frames of the stream processed per step (one trunk pass with per-sample DAM "
                          "statistics, SAM frame by frame in stream order; every frame's result is bit-identical to one-frame steps, "
                          "tests/test_gpu_net.py::test_stream_mode_is_bit_identical_to_batch1_steps).  1 = one frame per step.")

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const u32x4* __res
       const int iw = ow * 2 - 1 + kw;
       if ((unsigned)iw >= (unsigned)W) continue;
       float v[8];
-      unpack_bf16x8(__builtin_nontemporal_load(&raw[((int64_t)(n * H + ih) * W + iw) * C8 + oct]), v);
+      unpack_bf16x8(raw[((int64_t)(n * H + ih) * W + iw) * C8 + oct], v);
 #pragma unroll
       for (int i = 0; i < 8; ++i) best[i] = fmaxf(best[i], fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f));
     }

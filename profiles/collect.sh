@@ -7,7 +7,7 @@ set -e -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_r1c
 mkdir -p $O
-FIF=${FIF:-6}
+FIF=${FIF:-15}
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- \
   python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency-mode --no-calibration --frames-in-flight $FIF > $O/trace.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- \
