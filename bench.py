@@ -252,8 +252,9 @@ def main():
                            "event_pair_overhead_us_subtracted": conv_profile.empty_pair_us}
         if args.dump:
             with open(args.dump, "w") as f:
-                json.dump([dict(name=n, gflop=fl / 1e9, us=float(m) * 1e3, tflops=fl / (float(m) * 1e-3) / 1e12)
-                           for (n, fl), m in zip(meta, ms)], f, indent=0)
+                json.dump(dict(tiles={str(k): v for k, v in eng.tile_cache.items()},
+                               launches=[dict(name=n, gflop=fl / 1e9, us=float(m) * 1e3, tflops=fl / (float(m) * 1e-3) / 1e12)
+                                         for (n, fl), m in zip(meta, ms)]), f, indent=0)
     del eng, frames
     if rank == 0 and world == 1 and fif > 1 and not args.no_latency_mode:
         # the same stream with ONE frame per step (no look-ahead): the latency-bound form of configs[1]

@@ -72,10 +72,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
   // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
   // run of logical tile ids (N tiles of one M tile share the gathered A rows in that XCD's L2).
   int bid = blockIdx.x;
+#ifndef DIGA_NO_XCD_REMAP
   {
     const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+#endif
   const int mtile = bid / p.ntiles_n, ntile = bid - mtile * p.ntiles_n;
   // M tiles never straddle samples: tile -> (sample, tile within the sample).  A sample's rows are tiled from
   // its own row 0, so its results (and its 32-row statistics units) do not depend on the batch it rides in.
@@ -209,11 +211,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
       for (int b = 0; b < NT; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(bB + b * 32 * ROWB + coff);
       if (ILV && more)                  // this group's share of the next K step's loads, in the shadow of the MFMAs below
         issue_pieces(fill, std::integral_constant<int, s * LPT / KS>{}, std::integral_constant<int, (s + 1) * LPT / KS>{});
+#ifdef DIGA_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+#ifdef DIGA_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     };
     ksub(std::integral_constant<int, 0>{});
     ksub(std::integral_constant<int, 1>{});
@@ -328,7 +336,10 @@ const TileCfg kTiles[] = {{1, 128, 128, 4}, {11, 128, 128, 3}, {21, 128, 128, 2}
                           // loads interleaved with the MFMA groups (pays for the 8-wave tiles only; 4-wave 256x256 tiles -- one
                           // wave per SIMD, 256 accumulator registers -- were measured 15-25 % slower and are not built)
                           {46, 256, 128, 2, 64, true}, {47, 128, 256, 2, 64, true}, {48, 256, 256, 2, 64, true},
-                          {56, 256, 128, 4, 32, true}, {57, 128, 256, 4, 32, true}, {58, 256, 256, 4, 32, true}};
+                          {56, 256, 128, 4, 32, true}, {57, 128, 256, 4, 32, true}, {58, 256, 256, 4, 32, true},
+                          // ids 6x: 32-channel steps with only 2 buffers -- half the LDS, so that two (four) blocks share a CU and
+                          // one block's epilogue overlaps another's K loop (the short-K 1x1 convs: K = 256 is 4-8 steps per tile)
+                          {61, 128, 128, 2, 32, false}, {64, 64, 128, 2, 32, false}, {66, 256, 128, 2, 32, true}, {67, 128, 256, 2, 32, true}};
 
 const TileCfg* find_tile(int id) {
   for (const auto& t : kTiles)
@@ -461,6 +472,10 @@ extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, con
     case 56: e = launch_cfg<256, 128, 4, 2, 4, 32, true>(p, d->splitk, f32, stats, st); break;
     case 57: e = launch_cfg<128, 256, 2, 4, 4, 32, true>(p, d->splitk, f32, stats, st); break;
     case 58: e = launch_cfg<256, 256, 2, 4, 4, 32, true>(p, d->splitk, f32, stats, st); break;
+    case 61: e = launch_cfg<128, 128, 2, 2, 2, 32, false>(p, d->splitk, f32, stats, st); break;
+    case 64: e = launch_cfg<64, 128, 2, 2, 2, 32, false>(p, d->splitk, f32, stats, st); break;
+    case 66: e = launch_cfg<256, 128, 4, 2, 2, 32, true>(p, d->splitk, f32, stats, st); break;
+    case 67: e = launch_cfg<128, 256, 2, 4, 2, 32, true>(p, d->splitk, f32, stats, st); break;
   }
 #undef DIGA_TILE_CASES
   if (e) return e;

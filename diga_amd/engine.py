@@ -307,7 +307,7 @@ class Engine:
 
     TILE_CANDIDATES = {23: 64, 13: 64, 22: 64, 12: 64, 24: 128, 14: 128, 21: 128, 26: 128, 16: 128, 27: 256, 17: 256, 28: 256,
                        33: 64, 32: 64, 34: 128, 31: 128, 36: 128, 37: 256, 38: 256,
-                       46: 128, 47: 256, 48: 256, 56: 128, 57: 256, 58: 256}   # id -> N tile
+                       46: 128, 47: 256, 48: 256, 56: 128, 57: 256, 58: 256, 61: 128, 64: 128, 66: 128, 67: 256}   # id -> N tile
 
     def _tune(self, d, x, wgt, out, bn, reps=3):
         best, best_t = 0, float("inf")

@@ -118,7 +118,7 @@ def test_conv_results_do_not_depend_on_tile_or_batch():
         return out.view(torch.int16).cpu().reshape(b, -1), slab.cpu().reshape(b, -1)
 
     o0, s0 = run(x, 23)
-    for tile in (1, 12, 24, 3, 21, 26, 16, 27, 17, 28, 31, 32, 33, 34, 36, 37, 38, 46, 47, 48, 56, 57, 58):
+    for tile in (1, 12, 24, 3, 21, 26, 16, 27, 17, 28, 31, 32, 33, 34, 36, 37, 38, 46, 47, 48, 56, 57, 58, 61, 64, 66, 67):
         o, sl = run(x, tile)
         assert torch.equal(o, o0) and torch.equal(sl.view(torch.int32), s0.view(torch.int32)), tile
     for b in range(B):
