@@ -34,6 +34,10 @@ struct ConvKParams {
   void* out;
   float* slab;
   const float* shift;
+  const float* ep_scale;     // EPI_FUSED_APPLY: affine [C] or [nsamples][C] (ep_affine_stride = C), residual bf16 [M][Cout]
+  const float* ep_shift;
+  const void* ep_res;
+  int ep_affine_stride, ep_relu;
   int H, W, Cin, Ho, Wo, Cout, stride, ntaps;
   int M, K, cout_pad, hw, tiles_per_sample, units_per_sample, nk_total, nk_per_split, mtiles, ntiles_n;
   unsigned in_bytes, wgt_bytes;
@@ -48,8 +52,14 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int S, int BK, bool ILV, bool OUT_F32, bool STATS>
+// Epilogue modes: 0 = bf16 output + statistics (the trunk), 1 = fp32 output (head GEMM / split-K partials),
+// 2 = bf16 output only, 3 = statistics only (nothing stored: pass 1 of a recomputed conv3), 4 = fused DAM apply:
+// out = relu(acc*scale[c] + shift[c] + residual) in bf16, straight from the fp32 accumulators (pass 2).
+enum { EPI_BF16_STATS = 0, EPI_F32 = 1, EPI_BF16 = 2, EPI_STATS_ONLY = 3, EPI_FUSED_APPLY = 4 };
+
+template <int BM, int BN, int WM, int WN, int S, int BK, bool ILV, int EPI>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKParams p) {
+  constexpr bool OUT_F32 = EPI == EPI_F32, STATS = EPI == EPI_BF16_STATS || EPI == EPI_STATS_ONLY;
   constexpr int NW = WM * WN, NTHR = 64 * NW;        // 4 or 8 waves
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -290,22 +300,52 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
           if (rem < p.hw) out[(size_t)(m_base + rem) * p.cout_pad + c] = acc[a][b][r];
         }
       }
-  } else {
+  } else if constexpr (EPI != EPI_STATS_ONLY) {
     unsigned short* sC = reinterpret_cast<unsigned short*>(smem);   // [BM][BN] bf16
+    constexpr int CPR = BN / 8;                       // 16-byte chunks per tile row
+    if constexpr (EPI == EPI_FUSED_APPLY) {
+      // the residual tile comes in first, with coalesced 16-byte loads (read for the last time: non-temporal)
+      const unsigned short* res = reinterpret_cast<const unsigned short*>(p.ep_res);
+#pragma unroll
+      for (int i = 0; i < BM * CPR / NTHR; ++i) {
+        const int id = tid + NTHR * i;
+        const int row = id / CPR, cc = id - row * CPR;
+        const int rem = r0 + row, c = n0 + cc * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (rem < p.hw && c < p.Cout)
+          v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(res + (size_t)(m_base + rem) * p.Cout + c));
+        *reinterpret_cast<u32x4*>(sC + row * BN + cc * 8) = v;
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < NT; ++b) {
         const int col = wn * WTN + b * 32 + l31;
+        float esc = 1.f, esh = 0.f;
+        if constexpr (EPI == EPI_FUSED_APPLY) {
+          const int c = n0 + col;
+          if (c < p.Cout) {
+            esc = p.ep_scale[(size_t)n_img * p.ep_affine_stride + c];
+            esh = p.ep_shift[(size_t)n_img * p.ep_affine_stride + c];
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          sC[row * BN + col] = f32_to_bf16_bits(acc[a][b][r]);
+          if constexpr (EPI == EPI_FUSED_APPLY) {
+            // the arithmetic of bn_apply_kernel<1> on the unrounded accumulator: y = fma(x, scale, shift) + residual
+            float y = fmaf(acc[a][b][r], esc, esh) + bf16_bits_to_f32(sC[row * BN + col]);
+            if (p.ep_relu) y = fmaxf(y, 0.f);
+            sC[row * BN + col] = f32_to_bf16_bits(y);
+          } else {
+            sC[row * BN + col] = f32_to_bf16_bits(acc[a][b][r]);
+          }
         }
       }
     __syncthreads();
     unsigned short* out = reinterpret_cast<unsigned short*>(p.out);
-    constexpr int CPR = BN / 8;                       // 16-byte chunks per tile row
 #pragma unroll
     for (int i = 0; i < BM * CPR / NTHR; ++i) {
       const int id = tid + NTHR * i;
@@ -358,28 +398,30 @@ int auto_tile(const diga_conv_desc* d) {
 }
 
 template <int BM, int BN, int WM, int WN, int S, int BK = 64, bool ILV = false>
-int launch_cfg(const ConvKParams& p, int splitk, bool out_f32, bool stats, hipStream_t st) {
+int launch_cfg(const ConvKParams& p, int splitk, int epi, hipStream_t st) {
   constexpr int main_bytes = S * (BM + BN) * BK * 2;
   constexpr int epi_bytes = BM * BN * 2;
   constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   dim3 grid(p.mtiles * p.ntiles_n, splitk), block(64 * WM * WN);
   static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
+#define DIGA_EPI_KERNEL(E) conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, E>
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_EPI_KERNEL(EPI_BF16_STATS)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_EPI_KERNEL(EPI_F32)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_EPI_KERNEL(EPI_BF16)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_EPI_KERNEL(EPI_STATS_ONLY)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_EPI_KERNEL(EPI_FUSED_APPLY)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  if (out_f32 && !stats)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, true, false>), grid, block, smem, st, p);
-  else if (!out_f32 && stats)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, false, true>), grid, block, smem, st, p);
-  else if (!out_f32 && !stats)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, false, false>), grid, block, smem, st, p);
-  else {
-    diga_set_error("diga_conv_igemm_bf16: statistics with fp32 split-K output are not supported");
-    return DIGA_EINVAL;
+  switch (epi) {
+    case EPI_BF16_STATS: hipLaunchKernelGGL((DIGA_EPI_KERNEL(EPI_BF16_STATS)), grid, block, smem, st, p); break;
+    case EPI_F32: hipLaunchKernelGGL((DIGA_EPI_KERNEL(EPI_F32)), grid, block, smem, st, p); break;
+    case EPI_BF16: hipLaunchKernelGGL((DIGA_EPI_KERNEL(EPI_BF16)), grid, block, smem, st, p); break;
+    case EPI_STATS_ONLY: hipLaunchKernelGGL((DIGA_EPI_KERNEL(EPI_STATS_ONLY)), grid, block, smem, st, p); break;
+    case EPI_FUSED_APPLY: hipLaunchKernelGGL((DIGA_EPI_KERNEL(EPI_FUSED_APPLY)), grid, block, smem, st, p); break;
+    default: diga_set_error("diga_conv_igemm_bf16: bad epilogue mode %d", epi); return DIGA_EINVAL;
   }
+#undef DIGA_EPI_KERNEL
   return DIGA_OK;
 }
 
@@ -409,11 +451,10 @@ extern "C" int diga_conv_stat_units(const diga_conv_desc* d) {
   return d->B * cdiv(d->Ho * d->Wo, 32);
 }
 
-extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, const void* wgt, void* out,
-                                    float* stat_slab, const float* stat_shift, void* stream) {
-  if (int e = validate(d, "diga_conv_igemm_bf16")) return e;
-  DIGA_CHECK_ARG(in && wgt && out, "diga_conv_igemm_bf16: NULL tensor");
-  DIGA_CHECK_ARG((stat_slab == nullptr) == (stat_shift == nullptr), "diga_conv_igemm_bf16: slab and shift go together");
+namespace {
+int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out, float* stat_slab, const float* stat_shift,
+             int epi, const float* ep_scale, const float* ep_shift, const void* ep_res, int ep_affine_stride, int ep_relu,
+             void* stream) {
   const TileCfg* t = find_tile(d->tile ? d->tile : auto_tile(d));
   DIGA_CHECK_ARG(t != nullptr, "diga_conv_igemm_bf16: unknown tile id %d", d->tile);
   DIGA_CHECK_ARG(d->cout_pad % t->BN == 0, "diga_conv_igemm_bf16: cout_pad %d not a multiple of tile N %d", d->cout_pad, t->BN);
@@ -423,6 +464,7 @@ extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, con
   p.out = out;
   p.slab = stat_slab;
   p.shift = stat_shift;
+  p.ep_scale = ep_scale, p.ep_shift = ep_shift, p.ep_res = ep_res, p.ep_affine_stride = ep_affine_stride, p.ep_relu = ep_relu;
   p.H = d->H, p.W = d->W, p.Cin = d->Cin, p.Ho = d->Ho, p.Wo = d->Wo, p.Cout = d->Cout;
   p.stride = d->stride, p.ntaps = d->ntaps;
   p.M = d->B * d->Ho * d->Wo;
@@ -442,43 +484,63 @@ extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, con
     p.dydx[i] = (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu));
   }
   hipStream_t st = (hipStream_t)stream;
-  const bool f32 = d->out_f32 != 0, stats = stat_slab != nullptr;
   int e = DIGA_OK;
 #define DIGA_TILE_CASES(base, BM, BN, WM, WN)                                                   \
-  case base: e = launch_cfg<BM, BN, WM, WN, 4>(p, d->splitk, f32, stats, st); break;          \
-  case base + 10: e = launch_cfg<BM, BN, WM, WN, 3>(p, d->splitk, f32, stats, st); break;     \
-  case base + 20: e = launch_cfg<BM, BN, WM, WN, 2>(p, d->splitk, f32, stats, st); break;
+  case base: e = launch_cfg<BM, BN, WM, WN, 4>(p, d->splitk, epi, st); break;          \
+  case base + 10: e = launch_cfg<BM, BN, WM, WN, 3>(p, d->splitk, epi, st); break;     \
+  case base + 20: e = launch_cfg<BM, BN, WM, WN, 2>(p, d->splitk, epi, st); break;
   switch (t->id) {
     DIGA_TILE_CASES(1, 128, 128, 2, 2)
     DIGA_TILE_CASES(2, 128, 64, 2, 2)
     DIGA_TILE_CASES(3, 64, 64, 2, 2)
     DIGA_TILE_CASES(4, 64, 128, 2, 2)
     DIGA_TILE_CASES(5, 128, 32, 4, 1)
-    case 16: e = launch_cfg<256, 128, 4, 2, 3>(p, d->splitk, f32, stats, st); break;
-    case 26: e = launch_cfg<256, 128, 4, 2, 2>(p, d->splitk, f32, stats, st); break;
-    case 17: e = launch_cfg<128, 256, 2, 4, 3>(p, d->splitk, f32, stats, st); break;
-    case 27: e = launch_cfg<128, 256, 2, 4, 2>(p, d->splitk, f32, stats, st); break;
-    case 28: e = launch_cfg<256, 256, 2, 4, 2>(p, d->splitk, f32, stats, st); break;
-    case 31: e = launch_cfg<128, 128, 2, 2, 4, 32>(p, d->splitk, f32, stats, st); break;
-    case 32: e = launch_cfg<128, 64, 2, 2, 4, 32>(p, d->splitk, f32, stats, st); break;
-    case 33: e = launch_cfg<64, 64, 2, 2, 4, 32>(p, d->splitk, f32, stats, st); break;
-    case 34: e = launch_cfg<64, 128, 2, 2, 4, 32>(p, d->splitk, f32, stats, st); break;
-    case 36: e = launch_cfg<256, 128, 4, 2, 4, 32>(p, d->splitk, f32, stats, st); break;
-    case 37: e = launch_cfg<128, 256, 2, 4, 4, 32>(p, d->splitk, f32, stats, st); break;
-    case 38: e = launch_cfg<256, 256, 2, 4, 4, 32>(p, d->splitk, f32, stats, st); break;
-    case 46: e = launch_cfg<256, 128, 4, 2, 2, 64, true>(p, d->splitk, f32, stats, st); break;
-    case 47: e = launch_cfg<128, 256, 2, 4, 2, 64, true>(p, d->splitk, f32, stats, st); break;
-    case 48: e = launch_cfg<256, 256, 2, 4, 2, 64, true>(p, d->splitk, f32, stats, st); break;
-    case 56: e = launch_cfg<256, 128, 4, 2, 4, 32, true>(p, d->splitk, f32, stats, st); break;
-    case 57: e = launch_cfg<128, 256, 2, 4, 4, 32, true>(p, d->splitk, f32, stats, st); break;
-    case 58: e = launch_cfg<256, 256, 2, 4, 4, 32, true>(p, d->splitk, f32, stats, st); break;
-    case 61: e = launch_cfg<128, 128, 2, 2, 2, 32, false>(p, d->splitk, f32, stats, st); break;
-    case 64: e = launch_cfg<64, 128, 2, 2, 2, 32, false>(p, d->splitk, f32, stats, st); break;
-    case 66: e = launch_cfg<256, 128, 4, 2, 2, 32, true>(p, d->splitk, f32, stats, st); break;
-    case 67: e = launch_cfg<128, 256, 2, 4, 2, 32, true>(p, d->splitk, f32, stats, st); break;
+    case 16: e = launch_cfg<256, 128, 4, 2, 3>(p, d->splitk, epi, st); break;
+    case 26: e = launch_cfg<256, 128, 4, 2, 2>(p, d->splitk, epi, st); break;
+    case 17: e = launch_cfg<128, 256, 2, 4, 3>(p, d->splitk, epi, st); break;
+    case 27: e = launch_cfg<128, 256, 2, 4, 2>(p, d->splitk, epi, st); break;
+    case 28: e = launch_cfg<256, 256, 2, 4, 2>(p, d->splitk, epi, st); break;
+    case 31: e = launch_cfg<128, 128, 2, 2, 4, 32>(p, d->splitk, epi, st); break;
+    case 32: e = launch_cfg<128, 64, 2, 2, 4, 32>(p, d->splitk, epi, st); break;
+    case 33: e = launch_cfg<64, 64, 2, 2, 4, 32>(p, d->splitk, epi, st); break;
+    case 34: e = launch_cfg<64, 128, 2, 2, 4, 32>(p, d->splitk, epi, st); break;
+    case 36: e = launch_cfg<256, 128, 4, 2, 4, 32>(p, d->splitk, epi, st); break;
+    case 37: e = launch_cfg<128, 256, 2, 4, 4, 32>(p, d->splitk, epi, st); break;
+    case 38: e = launch_cfg<256, 256, 2, 4, 4, 32>(p, d->splitk, epi, st); break;
+    case 46: e = launch_cfg<256, 128, 4, 2, 2, 64, true>(p, d->splitk, epi, st); break;
+    case 47: e = launch_cfg<128, 256, 2, 4, 2, 64, true>(p, d->splitk, epi, st); break;
+    case 48: e = launch_cfg<256, 256, 2, 4, 2, 64, true>(p, d->splitk, epi, st); break;
+    case 56: e = launch_cfg<256, 128, 4, 2, 4, 32, true>(p, d->splitk, epi, st); break;
+    case 57: e = launch_cfg<128, 256, 2, 4, 4, 32, true>(p, d->splitk, epi, st); break;
+    case 58: e = launch_cfg<256, 256, 2, 4, 4, 32, true>(p, d->splitk, epi, st); break;
+    case 61: e = launch_cfg<128, 128, 2, 2, 2, 32, false>(p, d->splitk, epi, st); break;
+    case 64: e = launch_cfg<64, 128, 2, 2, 2, 32, false>(p, d->splitk, epi, st); break;
+    case 66: e = launch_cfg<256, 128, 4, 2, 2, 32, true>(p, d->splitk, epi, st); break;
+    case 67: e = launch_cfg<128, 256, 2, 4, 2, 32, true>(p, d->splitk, epi, st); break;
   }
 #undef DIGA_TILE_CASES
   if (e) return e;
   DIGA_CHECK_LAUNCH("diga_conv_igemm_bf16");
   return DIGA_OK;
+}
+}  // namespace
+
+extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, const void* wgt, void* out,
+                                    float* stat_slab, const float* stat_shift, void* stream) {
+  if (int e = validate(d, "diga_conv_igemm_bf16")) return e;
+  DIGA_CHECK_ARG(in && wgt, "diga_conv_igemm_bf16: NULL tensor");
+  DIGA_CHECK_ARG((stat_slab == nullptr) == (stat_shift == nullptr), "diga_conv_igemm_bf16: slab and shift go together");
+  DIGA_CHECK_ARG(out || stat_slab, "diga_conv_igemm_bf16: no output and no statistics requested");
+  DIGA_CHECK_ARG(!(d->out_f32 && stat_slab), "diga_conv_igemm_bf16: statistics with fp32 split-K output are not supported");
+  const int epi = d->out_f32 ? EPI_F32 : (stat_slab ? (out ? EPI_BF16_STATS : EPI_STATS_ONLY) : EPI_BF16);
+  return run_conv(d, in, wgt, out, stat_slab, stat_shift, epi, nullptr, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int diga_conv_igemm_bf16_apply(const diga_conv_desc* d, const void* in, const void* wgt, void* out, const float* scale,
+                                          const float* shift, const void* res, int relu, int nsamples_affine, void* stream) {
+  if (int e = validate(d, "diga_conv_igemm_bf16_apply")) return e;
+  DIGA_CHECK_ARG(in && wgt && out && scale && shift && res, "diga_conv_igemm_bf16_apply: NULL tensor");
+  DIGA_CHECK_ARG(!d->out_f32 && d->splitk == 1, "diga_conv_igemm_bf16_apply: bf16 output, no split-K");
+  DIGA_CHECK_ARG(nsamples_affine == 0 || nsamples_affine == d->B, "diga_conv_igemm_bf16_apply: nsamples_affine must be 0 or B");
+  return run_conv(d, in, wgt, out, nullptr, nullptr, EPI_FUSED_APPLY, scale, shift, res, nsamples_affine ? d->Cout : 0, relu, stream);
 }

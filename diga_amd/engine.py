@@ -141,7 +141,7 @@ class Engine:
 
     def __init__(self, weights: NetWeights, B: int, H: int, W: int, bn_lambda: float = 0.8, group=None,
                  head_splitk: int = 4, confidence_threshold: float = 0.9, stream: bool = False, conv_tile: int = 0,
-                 autotune: bool = False):
+                 autotune: bool = False, fuse_conv3: bool = False):
         """stream=False: x is ONE batch of B samples -> the reference's batch semantics (half_first DAM statistics over
         the batch, prototypes pooled over the batch).  stream=True: x holds B CONSECUTIVE batch-1 frames of a stream
         ("frames in flight"): the trunk runs once over all of them with per-sample DAM statistics (DAM carries no
@@ -155,6 +155,12 @@ class Engine:
         # (tests/test_gpu_kernels.py::test_conv_results_do_not_depend_on_tile_or_batch), so this never changes results.
         self.autotune = bool(autotune) and conv_tile == 0
         self.tile_cache = {}
+        # fuse_conv3: "conv3 -> bn3 -> += residual -> relu" as two passes over the 1x1 GEMM (statistics only, then
+        # recompute + fused apply): the widest tensor of a bottleneck is never written raw and read back.  Blocks with a
+        # downsample branch (4 of 33) keep the three-kernel form.  Measured (15 frames in flight, same-box A/B): 631.6 vs
+        # 629.1 frames/s -- the statistics pass runs at 770 TFLOP/s but the residual read in the fused epilogue is not
+        # overlapped with the K loop (168 us against 133 + 131 us for conv3 + bn_apply), so it is off by default.
+        self.fuse_conv3 = bool(fuse_conv3)
         # stream + group: the B local samples are this rank's frames of B consecutive GLOBAL batches (one frame per rank
         # per batch): statistics are exchanged per batch, so every global batch keeps the reference's batch semantics
         self.w = weights
@@ -280,7 +286,9 @@ class Engine:
         call("diga_bn_apply", _p(raw), _p(sc), _p(sh), _p(res), _p(rsc), _p(rsh), _p(out), M, Cc, 1,
              self.B if self.stream else 0, _stream())
 
-    def _conv(self, name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn: BNP | None):
+    def _conv(self, name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn: BNP | None, apply=None):
+        """One trunk conv.  out=None: statistics only.  apply=(scale, shift, residual): pass 2 of a fused conv3
+        (diga_conv_igemm_bf16_apply; no statistics).  Returns the statistics units per sample."""
         d = ConvDesc()
         d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = self.B, Hin, Win, Cin, Ho, Wo, Cout
         d.stride = stride
@@ -292,16 +300,28 @@ class Engine:
             d.ntaps = 1
         d.cout_pad = Cout
         d.splitk, d.out_f32, d.tile = 1, 0, self.conv_tile
-        flops = 2 * self.B * Ho * Wo * Cout * Cin * d.ntaps
+        wgt = self.w.conv[name]
+        if apply is None:
+            def launch():
+                call("diga_conv_igemm_bf16", C.byref(d), _p(x), _p(wgt), _p(out), _p(self.slab), _p(bn.running_mean), _stream())
+            mode = "stats" if out is None else "conv"
+        else:
+            sc, sh, res = apply
+
+            def launch():
+                call("diga_conv_igemm_bf16_apply", C.byref(d), _p(x), _p(wgt), _p(out), _p(sc), _p(sh), _p(res), 1,
+                     self.B if self.stream else 0, _stream())
+            mode = "apply"
+        # algorithmic FLOPs are counted once per conv: the recomputation in pass 2 of a fused conv3 is overhead
+        flops = 0 if mode == "apply" else 2 * self.B * Ho * Wo * Cout * Cin * d.ntaps
         if self.autotune:
-            key = (Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3)
+            key = (Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, mode)
             if key not in self.tile_cache and not torch.cuda.is_current_stream_capturing():
-                self.tile_cache[key] = self._tune(d, x, self.w.conv[name], out, bn)
+                self.tile_cache[key] = self._tune(d, launch)
             d.tile = self.tile_cache.get(key, 0)
         ev = self._ev_start()
-        call("diga_conv_igemm_bf16", C.byref(d), _p(x), _p(self.w.conv[name]), _p(out), _p(self.slab), _p(bn.running_mean),
-             _stream())
-        self._ev_end(ev, name, flops)
+        launch()
+        self._ev_end(ev, name + (":apply" if mode == "apply" else ""), flops)
         self.conv_flops += flops
         return (Ho * Wo + 31) // 32          # statistics units per sample
 
@@ -309,7 +329,7 @@ class Engine:
                        33: 64, 32: 64, 34: 128, 31: 128, 36: 128, 37: 256, 38: 256,
                        46: 128, 47: 256, 48: 256, 56: 128, 57: 256, 58: 256, 61: 128, 64: 128, 66: 128, 67: 256}   # id -> N tile
 
-    def _tune(self, d, x, wgt, out, bn, reps=3):
+    def _tune(self, d, launch, reps=3):
         best, best_t = 0, float("inf")
         for tile, bn_tile in self.TILE_CANDIDATES.items():
             if d.cout_pad % bn_tile:
@@ -319,8 +339,7 @@ class Engine:
             for r in range(reps + 1):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                call("diga_conv_igemm_bf16", C.byref(d), _p(x), _p(wgt), _p(out), _p(self.slab) if bn is not None else None,
-                     _p(bn.running_mean) if bn is not None else None, _stream())
+                launch()
                 e1.record()
                 evs.append((e0, e1))
             torch.cuda.synchronize()
@@ -385,19 +404,24 @@ class Engine:
                 sc, sh = self._finalize(bn2, nt, rows)
                 self._apply(self.raw2, sc, sh, None, None, None, self.act2, M, pl)
                 self._tap(pre + ".act2", self.act2, (B, Ho, Wo, pl))
-                # conv3 (1x1) -> bn3
+                # conv3 (1x1) -> bn3 (+ residual, relu)
                 bn3 = w.bn[pre + ".bn3"]
-                nt = self._conv(pre + ".conv3", self.act2, self.raw3, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)
-                self._tap(pre + ".conv3", self.raw3, (B, Ho, Wo, pl * 4))
-                sc3, sh3 = self._finalize(bn3, nt, rows)
-                if b == 0:    # downsample branch: 1x1 (stride) + bn on the block input
-                    bnd = w.bn[pre + ".downsample.1"]
-                    nt = self._conv(pre + ".downsample.0", cur, self.rawd, Hc, Wc, Cc, Ho, Wo, pl * 4, s, 1, False, bnd)
-                    self._tap(pre + ".downsample.0", self.rawd, (B, Ho, Wo, pl * 4))
-                    scd, shd = self._finalize(bnd, nt, rows)
-                    self._apply(self.raw3, sc3, sh3, self.rawd, scd, shd, nxt, M, pl * 4)
+                if self.fuse_conv3 and b != 0:
+                    nt = self._conv(pre + ".conv3", self.act2, None, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)      # statistics
+                    sc3, sh3 = self._finalize(bn3, nt, rows)
+                    self._conv(pre + ".conv3", self.act2, nxt, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, None, apply=(sc3, sh3, cur))
                 else:
-                    self._apply(self.raw3, sc3, sh3, cur, None, None, nxt, M, pl * 4)
+                    nt = self._conv(pre + ".conv3", self.act2, self.raw3, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)
+                    self._tap(pre + ".conv3", self.raw3, (B, Ho, Wo, pl * 4))
+                    sc3, sh3 = self._finalize(bn3, nt, rows)
+                    if b == 0:    # downsample branch: 1x1 (stride) + bn on the block input
+                        bnd = w.bn[pre + ".downsample.1"]
+                        nt = self._conv(pre + ".downsample.0", cur, self.rawd, Hc, Wc, Cc, Ho, Wo, pl * 4, s, 1, False, bnd)
+                        self._tap(pre + ".downsample.0", self.rawd, (B, Ho, Wo, pl * 4))
+                        scd, shd = self._finalize(bnd, nt, rows)
+                        self._apply(self.raw3, sc3, sh3, self.rawd, scd, shd, nxt, M, pl * 4)
+                    else:
+                        self._apply(self.raw3, sc3, sh3, cur, None, None, nxt, M, pl * 4)
                 cur, nxt = nxt, cur
                 Hc, Wc, Cc = Ho, Wo, pl * 4
                 self._tap(pre, cur, (B, Ho, Wo, Cc))
@@ -418,7 +442,8 @@ class Engine:
         if self.autotune:
             key = ("head", cin)
             if key not in self.tile_cache and not torch.cuda.is_current_stream_capturing():
-                self.tile_cache[key] = self._tune(d, feat, hw, self.head_part, None)
+                self.tile_cache[key] = self._tune(d, lambda: call("diga_conv_igemm_bf16", C.byref(d), _p(feat), _p(hw), _p(self.head_part),
+                                                                  None, None, _stream()))
             d.tile = self.tile_cache.get(key, 0)
         flops = 2 * self.P * self.C * cin * 18
         ev = self._ev_start()

@@ -67,6 +67,17 @@ int diga_conv_stat_units(const diga_conv_desc* desc);
  * reference's half_first groups is decided in diga_bn_finalize, not here. */
 int diga_conv_igemm_bf16(const diga_conv_desc* desc, const void* in, const void* wgt, void* out,
                          float* stat_slab, const float* stat_shift, void* stream);
+/* out == NULL with a stat_slab: statistics only, nothing is stored.  Together with the entry point below this
+ * replaces "conv3 -> bn3 -> += residual -> relu" (adaptseg:93-100) by two passes over the same GEMM: pass 1 takes
+ * the DAM statistics, diga_bn_finalize makes the affine, pass 2 recomputes the conv and writes
+ *   out = relu?( acc*scale[c] + shift[c] + res )  (bf16)
+ * straight from the fp32 accumulators, so the widest tensor of a bottleneck is never written raw and read back
+ * (the 1x1 conv3 is cheap to recompute: 4.4 of a layer3 bottleneck's 18.7 GFLOP, against 6 of its 8 bytes per
+ * element of memory traffic).  res: bf16 [M][Cout] already-normalised residual; nsamples_affine: 0 = one affine [C],
+ * B = per-sample affines [B][C] (see diga_bn_finalize). */
+int diga_conv_igemm_bf16_apply(const diga_conv_desc* desc, const void* in, const void* wgt, void* out,
+                               const float* scale, const float* shift, const void* res, int relu,
+                               int nsamples_affine, void* stream);
 
 /* Stem (adaptseg:133,178): 7x7 stride 2 pad 3, 3 -> 64, fp32 NCHW input [B,3,H,W] -> raw bf16 NHWC
  * [B,Ho,Wo,64] + statistics slab [units][2][64] (sample-major, units/B per sample).

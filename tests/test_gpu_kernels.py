@@ -126,6 +126,48 @@ def test_conv_results_do_not_depend_on_tile_or_batch():
         assert torch.equal(o[0], o0[b]) and torch.equal(sl[0].view(torch.int32), s0[b].view(torch.int32)), b
 
 
+@pytest.mark.parametrize("B,per_sample,tile", [(1, 0, 0), (3, 1, 48), (2, 0, 24), (2, 1, 67)])
+def test_conv3_two_pass_fused_apply(B, per_sample, tile):
+    """conv3 -> bn3 -> += residual -> relu as two passes over the GEMM: pass 1 (out = NULL) leaves exactly the slab of the
+    storing kernel, pass 2 (diga_conv_igemm_bf16_apply) writes relu(acc*scale + shift + residual) from the fp32 accumulators."""
+    g = torch.Generator().manual_seed(31 + B)
+    H, W, Cin, Cout = 13, 21, 128, 512
+    x = bf16_round(torch.randn(B, Cin, H, W, generator=g).relu())
+    wt = bf16_round(torch.randn(Cout, Cin, 1, 1, generator=g) * 0.08)
+    res = bf16_round(torch.randn(B, Cout, H, W, generator=g).relu())
+    rm, rv, bw, bb = _bn_params(Cout, g)
+    d = conv_desc(B, H, W, Cin, Cout, tile=tile)
+    nu = call("diga_conv_stat_units", C.byref(d))
+    xin, wp, rin = to_nhwc_bf16(x), pack_conv_weight(wt).to(DEV), to_nhwc_bf16(res)
+    dv = [t.to(DEV) for t in (rm, rv, bw, bb)]
+    out = torch.zeros(B * H * W * Cout, dtype=torch.bfloat16, device=DEV)
+    slab_a = torch.full((nu * 2 * Cout,), float("nan"), dtype=torch.float32, device=DEV)
+    slab_b = torch.full((nu * 2 * Cout,), float("nan"), dtype=torch.float32, device=DEV)
+    call("diga_conv_igemm_bf16", C.byref(d), P(xin), P(wp), P(out), P(slab_a), P(dv[0]), stream())
+    call("diga_conv_igemm_bf16", C.byref(d), P(xin), P(wp), None, P(slab_b), P(dv[0]), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(slab_a.view(torch.int32), slab_b.view(torch.int32))
+    ns = B if per_sample else 1
+    sc = torch.empty(ns * Cout, dtype=torch.float32, device=DEV)
+    sh = torch.empty(ns * Cout, dtype=torch.float32, device=DEV)
+    if per_sample:
+        call("diga_bn_finalize", P(slab_b), nu // B, B, B, 1, Cout, float(H * W), 0.0, P(dv[0]), P(dv[1]), P(dv[2]), P(dv[3]), 0.8,
+             1e-5, P(sc), P(sh), stream())
+    else:
+        call("diga_bn_finalize", P(slab_b), nu // B, B, 1 if B > 1 else B, 0, Cout, float(H * W), float((B - 1) * H * W), P(dv[0]),
+             P(dv[1]), P(dv[2]), P(dv[3]), 0.8, 1e-5, P(sc), P(sh), stream())
+    y = torch.zeros(B * H * W * Cout, dtype=torch.bfloat16, device=DEV)
+    call("diga_conv_igemm_bf16_apply", C.byref(d), P(xin), P(wp), P(y), P(sc), P(sh), P(rin), 1, B if per_sample else 0, stream())
+    torch.cuda.synchronize()
+    conv = F.conv2d(x, wt)
+    scc, shc = sc.cpu().reshape(ns, Cout, 1, 1), sh.cpu().reshape(ns, Cout, 1, 1)
+    ref = torch.relu(conv * scc + shc + res)
+    assert rel_err(from_nhwc_bf16(y, (B, H, W, Cout)), bf16_round(ref)) <= BF16_TOL
+    for b in range(B if per_sample else 0):      # the affine itself, per sample, against the oracle
+        rsc, rsh = _oracle_scale_shift(conv[b:b + 1], rm, rv, bw, bb)
+        assert rel_err(sc.cpu()[b * Cout:(b + 1) * Cout], rsc) < 1e-4 and rel_err(sh.cpu()[b * Cout:(b + 1) * Cout], rsh) < 1e-4
+
+
 def test_conv_rejects_bad_shapes():
     from diga_amd._lib import DigaError
     d = conv_desc(1, 9, 17, 48, 64)       # Cin not a multiple of 64
