@@ -140,7 +140,7 @@ class Engine:
     """Static plan + buffers for one input shape (B, H, W) on the current device."""
 
     def __init__(self, weights: NetWeights, B: int, H: int, W: int, bn_lambda: float = 0.8, group=None,
-                 head_splitk: int = 4, confidence_threshold: float = 0.9, stream: bool = False, conv_tile: int = 0,
+                 confidence_threshold: float = 0.9, stream: bool = False, conv_tile: int = 0,
                  autotune: bool = False, fuse_conv3: bool = False):
         """stream=False: x is ONE batch of B samples -> the reference's batch semantics (half_first DAM statistics over
         the batch, prototypes pooled over the batch).  stream=True: x holds B CONSECUTIVE batch-1 frames of a stream
@@ -179,7 +179,6 @@ class Engine:
         self.h, self.wd = self.h3, self.w3
         self.hw = self.h * self.wd
         self.P = B * self.hw
-        self.head_splitk = head_splitk
         self.threshold = float(np.float32(confidence_threshold))
         dev = self.dev
         bf, f32, i32 = torch.bfloat16, torch.float32, torch.int32
