@@ -297,6 +297,55 @@ def test_stream_mode_is_bit_identical_to_batch1_steps(weights, H, W, K):
         assert bool((ek.hist == e1.hist).all()), ("hist", win)
 
 
+def test_two_windows_on_two_streams_are_bit_identical(weights):
+    """StreamWindows: two windows of K frames whose trunks run concurrently on two HIP streams (SAM in stream order, one
+    shared prototype state and metric) == 2K one-frame steps, bit for bit; two steps, the second replayed from a HIP graph."""
+    from diga_amd.pipeline import StreamWindows
+    H, W, K = 129, 257, 3
+    e1 = Engine(weights, 1, H, W)
+    sw = StreamWindows(weights, K, 2, H, W)
+    seq = []
+    for t in range(4 * K):
+        x, y = synth.synth_frame(60 + t, 1, H, W)
+        yd = torch.from_numpy(y).cuda()
+        p = e1.forward_and_adapt(torch.from_numpy(x).cuda(), yd, CFG)
+        e1.tail(yd)
+        torch.cuda.synchronize()
+        seq.append(p.cpu().clone())
+
+    def windows(step):
+        out = []
+        for w in range(2):
+            xy = [synth.synth_frame(60 + (2 * step + w) * K + j, 1, H, W) for j in range(K)]
+            out.append((torch.from_numpy(np.concatenate([a for a, _ in xy])).cuda(), torch.from_numpy(np.concatenate([b for _, b in xy])).cuda()))
+        return out
+
+    w0 = windows(0)
+    probs = sw.step(w0, CFG)
+    torch.cuda.synchronize()
+    got = [p.cpu().clone() for p in probs]
+    # second step: captured into a HIP graph (fork/join of the two streams inside the capture) and replayed
+    w1 = windows(1)
+    state = [t.clone() for t in (sw.engines[0].run_proto, sw.engines[0].run_flag, sw.engines[0].state_flag, sw.engines[0].hist)]
+    sw.step(w1, CFG)                       # warm-up of the same shapes outside the capture, then restore the state
+    torch.cuda.synchronize()
+    for dst, src in zip((sw.engines[0].run_proto, sw.engines[0].run_flag, sw.engines[0].state_flag, sw.engines[0].hist), state):
+        dst.copy_(src)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sw.step(w1, CFG)
+    for dst, src in zip((sw.engines[0].run_proto, sw.engines[0].run_flag, sw.engines[0].state_flag, sw.engines[0].hist), state):
+        dst.copy_(src)
+    g.replay()
+    torch.cuda.synchronize()
+    got += [p.cpu().clone() for p in probs]
+    for w in range(4):
+        for j in range(K):
+            a, b = got[w][j], seq[w * K + j][0]
+            assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), (w, j)
+    assert torch.equal(sw.engines[0].run_proto.cpu(), e1.run_proto.cpu()) and bool((sw.engines[0].hist == e1.hist).all())
+
+
 def test_module_stream_api_matches_test_step(diga):
     """DIGA.test_step_stream (K frames in flight) leaves the same metric and SAM state as K test_step calls."""
     m = diga
