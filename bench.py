@@ -110,20 +110,31 @@ def cpu_baseline(nframes_timed=10, H=512, W=1024):
                        f"confusion matrix), torch {torch.__version__} CPU")
 
 
-def run_config(args, world, rank, dev, group, weights, fif, steps, warmup):
-    """Build an engine for `fif` frames per step, time `steps` steps -> (fps, ms_per_step, engine, frames, use_graph)."""
+def run_config(args, world, rank, dev, group, weights, fif, steps, warmup, nwin=1):
+    """Build the engine(s) for `nwin` windows of `fif` frames per step, time `steps` steps
+    -> (fps, ms_per_step, first engine, frame windows, use_graph)."""
     from diga_amd import synth
     from diga_amd.engine import Engine
+    from diga_amd.pipeline import StreamWindows
     H, W = args.height, args.width
-    eng = Engine(weights, fif, H, W, bn_lambda=CFG["bn_lambda"], group=group, stream=fif > 1, autotune=not args.no_autotune)
+    if nwin > 1:
+        sw = StreamWindows(weights, fif, nwin, H, W, bn_lambda=CFG["bn_lambda"], autotune=not args.no_autotune)
+        eng = sw.engines[0]
+    else:
+        sw = None
+        eng = Engine(weights, fif, H, W, bn_lambda=CFG["bn_lambda"], group=group, stream=fif > 1, autotune=not args.no_autotune)
     nf = 4 if fif == 1 else 2
     frames = []
-    for i in range(nf):
+    for i in range(nf * nwin):
         xy = [synth.synth_frame(1000 + (i * fif + k) * world + rank, 1, H, W) for k in range(fif)]
         frames.append((torch.from_numpy(np.concatenate([a for a, _ in xy])).to(dev),
                        torch.from_numpy(np.concatenate([b for _, b in xy])).to(dev)))
 
     def step_eager(i):
+        if sw is not None:
+            j = (i % nf) * nwin
+            sw.step(frames[j:j + nwin], CFG)
+            return
         x, y = frames[i % nf]
         eng.forward_and_adapt(x, y, CFG)
         eng.tail(y)
@@ -170,7 +181,7 @@ def run_config(args, world, rank, dev, group, weights, fif, steps, warmup):
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    return world * fif * steps / dt, dt / steps * 1e3, eng, frames, use_graph
+    return world * fif * nwin * steps / dt, dt / steps * 1e3, eng, frames, use_graph
 
 
 def main():
@@ -184,6 +195,9 @@ def main():
                     help="consecutive batch-1 frames of the stream processed per step (one trunk pass with per-sample DAM "
                          "statistics, SAM frame by frame in stream order; every frame's result is bit-identical to one-frame steps, "
                          "tests/test_gpu_net.py::test_stream_mode_is_bit_identical_to_batch1_steps).  1 = one frame per step.")
+    ap.add_argument("--windows", type=int, default=2,
+                    help="N=1 only: windows of --frames-in-flight frames per step, each window's trunk on its own HIP stream "
+                         "(diga_amd/pipeline.py; SAM stays in stream order, results bit-identical to one-frame steps)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-autotune", action="store_true", help="fixed tile rule instead of timing the tile candidates per conv shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -217,7 +231,8 @@ def main():
     H, W = args.height, args.width
     weights = NetWeights(synth.synth_params(0), dev)
     fif = max(1, args.frames_in_flight)
-    fps, ms_per_step, eng, frames, use_graph = run_config(args, world, rank, dev, group, weights, fif, args.steps, args.warmup)
+    nwin = max(1, args.windows) if world == 1 else 1
+    fps, ms_per_step, eng, frames, use_graph = run_config(args, world, rank, dev, group, weights, fif, args.steps, args.warmup, nwin)
 
     res = {
         "metric": "adapted frames/sec DeepLabV2-R101 DIGA (DAM+SAM) 1024x512", "value": round(fps, 2), "unit": "frames/s",
@@ -225,14 +240,14 @@ def main():
         "step_ms": run_config.step_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": ("BASELINE configs[1]: DIGA TTA stream (DAM+SAM, 19 classes), batch 1, online per-frame prototype/BN-stat "
-                                "updates" + (f"; {fif} consecutive frames in flight per step (per-sample DAM statistics, sequential SAM; "
-                                             "bit-identical to one-frame steps)" if fif > 1 else "; one frame per step") if world == 1 else
+                                "updates" + (f"; {nwin} window(s) of {fif} consecutive frames in flight per step (per-sample DAM statistics, "
+                                             "SAM in stream order; bit-identical to one-frame steps)" if fif * nwin > 1 else "; one frame per step") if world == 1 else
                                 f"BASELINE configs[2]: global batch {world} = 1 frame per GPU, BN sum/sumsq + prototype sums all-reduced (RCCL)"
                                 + (f"; {fif} consecutive global batches in flight per step (one exchange per BN layer for all of them)" if fif > 1 else "")),
                    "resolution": f"{W}x{H}", "feature_grid": f"{eng.wd}x{eng.h}", "weights": "seeded synthetic init (diga_amd/synth.py)",
                    "launch": "hipGraph replay" if use_graph else "eager", "backend": backend if world > 1 else None, "conv_tiles": "autotuned per shape" if eng.autotune else "fixed rule",
                    "includes": "net + SAM + fusion + upsample/argmax/confusion tail",
-                   "frames_per_step": fif, "conv_gflop_per_frame": round(eng.conv_flops / fif / 1e9, 3)},
+                   "frames_per_step": fif * nwin, "windows": nwin, "conv_gflop_per_frame": round(eng.conv_flops / fif / 1e9, 3)},
     }
     if rank == 0 and world == 1 and not args.no_roofline:
         meta, ms = conv_profile(eng, frames, CFG)
@@ -256,7 +271,7 @@ def main():
                                launches=[dict(name=n, gflop=fl / 1e9, us=float(m) * 1e3, tflops=fl / (float(m) * 1e-3) / 1e12)
                                          for (n, fl), m in zip(meta, ms)]), f, indent=0)
     del eng, frames
-    if rank == 0 and world == 1 and fif > 1 and not args.no_latency_mode:
+    if rank == 0 and world == 1 and fif * nwin > 1 and not args.no_latency_mode:
         # the same stream with ONE frame per step (no look-ahead): the latency-bound form of configs[1]
         f1, ms1, e1, _, _ = run_config(args, world, rank, dev, group, weights, 1, max(10, args.steps), min(args.warmup, 10))
         res["one_frame_per_step"] = {"value": round(f1, 2), "unit": "frames/s", "ms_per_step": round(ms1, 4)}
