@@ -15,6 +15,8 @@ src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r1c"
 fif = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 here = os.path.dirname(os.path.abspath(__file__))
 shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(here, "r1c_bench_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "trace2", "t_kernel_stats.csv")):      # default command: two windows, kernels overlap
+    shutil.copy(os.path.join(src, "trace2", "t_kernel_stats.csv"), os.path.join(here, "r1c_bench_2windows_kernel_stats.csv"))
 
 
 def last_step(path, counter, launches):
