@@ -201,6 +201,39 @@ int diga_proto_classify_fuse(const void* feat, const float* logits, const float*
                              float pl1, float fl, float fl1, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Optional SAM extension (BASELINE.json north_star (2)).  NO counterpart in the reference: DIGA as
+ * published has no connected-component step, the default path never calls these, and with respect to the
+ * reference their results are "parity unpinned".  Specification (the build's own), pinned against
+ * scipy.ndimage.label (tests/golden/fn_ccl.npz):
+ * ------------------------------------------------------------------------------------------ */
+/* Connected components of the per-class masks of a label map, union-find with canonical labels.
+ * labels: int32, sample b at labels + b*label_sample_stride (0 = h*w, dense), h*w values each; a value in
+ *   [0, C) puts the pixel in that class's mask, anything else (255 = ignore) is background.
+ * connectivity: 4 or 8.
+ * inst: int32 [B][h*w]: 0 = background, else the number of the pixel's component inside ITS class's mask, counted
+ *   from 1 in raster order of the components' first pixels  (== scipy.ndimage.label(labels[b] == c, structure)).
+ * ncomp: int32 [B][C] components per class.  work: diga_ccl_work_bytes() bytes of scratch.
+ * Frames of up to 36 864 pixels (every feature grid of the net) run in one launch on an LDS-resident parent
+ * array, larger ones through global memory; force_global != 0 takes the second path regardless (tests). */
+int64_t diga_ccl_work_bytes(int B, int h, int w, int C);
+int diga_ccl_label(const int32_t* labels, int64_t label_sample_stride, int B, int h, int w, int C,
+                   int connectivity, int32_t* inst, int32_t* ncomp, void* work, int force_global,
+                   void* stream);
+
+/* Instance-masked prototype pooling: the mean feature row of every component found by diga_ccl_label.
+ * feat: bf16 [B*hw][CH] (CH % 8 == 0); labels / inst / ncomp as above.  Row g of the instance table is component
+ * (sample b, class c, number i) with g = (number of components before (b, c) in (sample, class) order) + i - 1.
+ * protos: fp32 [max_inst][CH] (rows >= min(total, max_inst) are not written); counts (pixels), inst_class,
+ * inst_sample: int32 [max_inst] (0 / -1 / -1 in unused rows); n_total: int32 [1] = number of components found --
+ * when it exceeds max_inst the surplus rows were dropped.  Stable pixel-order lists and fixed-order sums:
+ * deterministic, no floating-point atomics.  work: diga_instance_pool_work_bytes() bytes. */
+int64_t diga_instance_pool_work_bytes(int B, int64_t hw, int C, int CH, int max_inst);
+int diga_instance_pool(const void* feat, const int32_t* labels, int64_t label_sample_stride,
+                       const int32_t* inst, const int32_t* ncomp, int B, int64_t hw, int C, int CH,
+                       int max_inst, float* protos, int32_t* counts, int32_t* inst_class,
+                       int32_t* inst_sample, int32_t* n_total, void* work, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Tail (ttda:1610, 158-173): bilinear upsample (align_corners=False) + argmax + confusion matrix.
  * probs fp32 NCHW [B,C,h,w]; target int64/int32 [B,H,W]; pred uint8 [B,H,W] (may be NULL);
  * hist int64 [C*C] += bincount(C*target+pred) * B for 0 <= target < C; probs_up (may be NULL)

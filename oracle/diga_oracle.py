@@ -378,3 +378,87 @@ def map_labels(label_ids, label2train):
     for source_label, target_label in mapping:
         map_vector[source_label] = target_label
     return map_vector[np.asarray(label_ids).astype(np.int64, copy=False)]
+
+
+# ------------------------------------------------------------------------------------------------
+# Optional component: connected components of the per-class masks + instance-masked pooling.
+# The reference has NO such code: with respect to Waybaba/DIGA this is "parity unpinned".  The
+# specification is the build's own (BASELINE.json north_star (2)): per-class binary masks, 4- or 8-connectivity,
+# components numbered from 1 inside each class in raster order of their first pixel, background 0.  Pinned
+# against scipy.ndimage.label (scipy 1.15.3) outputs committed in tests/golden/fn_ccl.npz (oracle/gen_golden_ccl.py).
+# ------------------------------------------------------------------------------------------------
+def ccl_label(labels, num_classes: int = NUM_CLASSES, connectivity: int = 8):
+    """labels int [B,h,w] -> (inst int32 [B,h,w], ncomp int32 [B,C]).  Run-based two-pass union-find: the runs of a
+    row are united with the overlapping same-class runs of the row above; the root of a set is its lowest-numbered
+    run (runs are numbered in raster order), so roots appear in raster order of the components' first pixels."""
+    assert connectivity in (4, 8)
+    lab_all = np.asarray(labels)
+    B, h, w = lab_all.shape
+    inst = np.zeros((B, h, w), dtype=np.int32)
+    ncomp = np.zeros((B, num_classes), dtype=np.int32)
+    reach = 1 if connectivity == 8 else 0
+    for b in range(B):
+        lab = lab_all[b]
+        parent, runs = [], []          # runs[i] = (y, x0, x1, class)
+
+        def find(i):
+            while parent[i] != i:
+                parent[i] = parent[parent[i]]
+                i = parent[i]
+            return i
+
+        prev = []
+        for y in range(h):
+            row = lab[y]
+            cut = np.flatnonzero(row[1:] != row[:-1]) + 1
+            starts = np.concatenate(([0], cut))
+            ends = np.concatenate((cut, [w]))
+            cur = []
+            k = 0                       # first run of the previous row that can still touch
+            for x0, x1 in zip(starts.tolist(), ends.tolist()):
+                c = int(row[x0])
+                if not 0 <= c < num_classes:
+                    continue
+                i = len(parent)
+                parent.append(i)
+                runs.append((y, x0, x1, c))
+                cur.append(i)
+                while k < len(prev) and runs[prev[k]][2] + reach <= x0:      # ends left of this run: never touches later ones
+                    k += 1
+                j = k
+                while j < len(prev) and runs[prev[j]][1] < x1 + reach:
+                    if runs[prev[j]][3] == c and runs[prev[j]][2] + reach > x0:
+                        a, r = find(prev[j]), find(i)
+                        if a != r:
+                            parent[max(a, r)] = min(a, r)
+                    j += 1
+            prev = cur
+        number = {}
+        for i, (y, x0, x1, c) in enumerate(runs):
+            r = find(i)
+            if r == i:
+                ncomp[b, c] += 1
+                number[i] = ncomp[b, c]
+            inst[b, y, x0:x1] = number[r]
+    return inst, ncomp
+
+
+def instance_prototypes(feature, labels, inst, ncomp, num_classes: int = NUM_CLASSES):
+    """Instance-masked pooling: the mean feature of every component, rows ordered (sample, class, component number).
+    feature [B,CH,h,w] float; -> (protos float64 [N,CH], counts int64 [N], cls int32 [N], sample int32 [N])."""
+    f = np.asarray(feature, dtype=np.float64)
+    B, CH, h, w = f.shape
+    f = f.transpose(0, 2, 3, 1).reshape(B, h * w, CH)
+    lab, ins = np.asarray(labels).reshape(B, -1), np.asarray(inst).reshape(B, -1)
+    protos, counts, cls, smp = [], [], [], []
+    for b in range(B):
+        for c in range(num_classes):
+            for i in range(1, int(ncomp[b, c]) + 1):
+                m = (lab[b] == c) & (ins[b] == i)
+                protos.append(f[b][m].mean(0))
+                counts.append(int(m.sum()))
+                cls.append(c)
+                smp.append(b)
+    if not protos:
+        return np.zeros((0, CH)), np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32)
+    return np.stack(protos), np.array(counts, np.int64), np.array(cls, np.int32), np.array(smp, np.int32)

@@ -50,6 +50,11 @@ def gold_input():
 
 
 @pytest.fixture(scope="session")
+def gold_ccl():
+    return load_golden("fn_ccl.npz")
+
+
+@pytest.fixture(scope="session")
 def synth_params_np():
     from diga_amd import synth
     return synth.synth_params(0)

@@ -211,3 +211,32 @@ def test_input_pipeline(gold_input):
         assert np.array_equal(O.preprocess_image(img, mean, False), g[f"bdd_{tag}"])
     assert np.array_equal(O.map_labels(g["ids"], g["label2train"]), g["train_ids"])
     assert np.array_equal(data.map_vector()[g["ids"].astype(np.int64)], g["train_ids"])
+
+
+def test_ccl_against_scipy_fixture(gold_ccl):
+    """The optional connected-component restatement (no counterpart in the reference) against the
+    scipy.ndimage.label vectors of tests/golden/fn_ccl.npz (oracle/gen_golden_ccl.py): bit-exact, both connectivities;
+    when scipy is importable the same check is repeated live on a fresh label map."""
+    g = gold_ccl
+    for tag in ("tiny", "feat", "noisy", "wide", "shapes"):
+        for conn in (4, 8):
+            inst, ncomp = O.ccl_label(g[f"{tag}_labels"], int(g[f"{tag}_C"]), conn)
+            assert np.array_equal(inst, g[f"{tag}_inst{conn}"]) and np.array_equal(ncomp, g[f"{tag}_ncomp{conn}"]), (tag, conn)
+    ndimage = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(2)
+    lab = rng.integers(0, 3, (1, 50, 70)).astype(np.int32)
+    for conn in (4, 8):
+        inst, ncomp = O.ccl_label(lab, 3, conn)
+        for c in range(3):
+            l, n = ndimage.label(lab[0] == c, structure=ndimage.generate_binary_structure(2, 1 if conn == 4 else 2))
+            assert n == ncomp[0, c] and np.array_equal(np.where(lab[0] == c, inst[0], 0), l)
+
+
+def test_instance_prototypes_oracle():
+    lab = np.array([[[0, 0, 255, 1], [1, 0, 255, 1], [1, 255, 0, 0]]], dtype=np.int32)
+    inst, ncomp = O.ccl_label(lab, 2, 4)
+    assert ncomp.tolist() == [[2, 2]]
+    feat = np.arange(12, dtype=np.float32).reshape(1, 1, 3, 4)
+    protos, counts, cls, smp = O.instance_prototypes(feat, lab, inst, ncomp, 2)
+    assert counts.tolist() == [3, 2, 2, 2] and cls.tolist() == [0, 0, 1, 1] and smp.tolist() == [0, 0, 0, 0]
+    assert np.allclose(protos[:, 0], [(0 + 1 + 5) / 3, (10 + 11) / 2, (3 + 7) / 2, (4 + 8) / 2])
