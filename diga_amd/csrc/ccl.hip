@@ -11,8 +11,8 @@
 //   compress + count   roots per (256-pixel block, class) by wave ballots               -> blockcnt, rank inside block
 //   scan     per (sample, class) exclusive scan over the blocks                         -> blockbase, ncomp
 //   gather   inst[p] = blockbase[block of root][class] + rank[root] + 1   (raster order of first pixels, per class)
-//   Frames whose parent array fits in LDS (h*w <= 36864: every feature grid of the net) take ONE launch instead: one
-//   block per sample runs the same phases on an LDS-resident parent array.
+//   (A one-launch variant -- one block per sample, parent array in LDS -- was measured SLOWER than these six launches:
+//   57 us against 28 us for fifteen 65x129 frames, one CU walking its frame in nine serial strides; it is not built.)
 // diga_instance_pool: stable per-instance pixel lists (one wave per instance walks [first, last] of its pixels),
 //   chunked register-accumulated row sums, fixed-order reduce -> deterministic means, no float atomics.
 #include "common.h"
@@ -20,8 +20,6 @@
 namespace {
 
 constexpr int CCL_BLK = 256;      // pixels per block of the global path
-constexpr int CCL_LDS_MAX = 36864;  // pixels whose parent array (int32) fits one block's LDS (144 KiB)
-constexpr int CCL_LDS_THREADS = 1024;
 constexpr int IP_CS = 64;         // list positions per pooling job
 
 __device__ __forceinline__ int cls_of(int v, int C) { return (unsigned)v < (unsigned)C ? v : -1; }
@@ -50,28 +48,6 @@ __device__ __forceinline__ void g_unite(int* L, int a, int b) {
     b = old;                        // b was re-parented meanwhile: carry on from its new parent
   }
 }
-// the same on an LDS-resident array (one block)
-__device__ __forceinline__ int s_find(volatile int* L, int i) {
-  int p;
-  while ((p = L[i]) != i) i = p;
-  return i;
-}
-__device__ __forceinline__ void s_unite(int* L, int a, int b) {
-  for (;;) {
-    a = s_find(L, a);
-    b = s_find(L, b);
-    if (a == b) return;
-    if (a > b) {
-      const int t = a;
-      a = b;
-      b = t;
-    }
-    const int old = atomicMin(L + b, a);
-    if (old == b) return;
-    b = old;
-  }
-}
-
 // same-class flags of the four scan-mask neighbours of pixel (x, y) of class c
 struct Nbr {
   bool w, n, nw, ne;
@@ -124,15 +100,24 @@ __global__ __launch_bounds__(CCL_BLK) void ccl_init_kernel(const int32_t* __rest
   L[p] = first_parent(neighbours(lab, p, x, y, w, c, conn8), p, w);
 }
 
-__global__ __launch_bounds__(CCL_BLK) void ccl_compress_kernel(int hw, int* __restrict__ parent) {
+// Root by plain (L2-cached) loads, for the launches in which nobody unites: the parents were written by an EARLIER launch
+// (visible after the kernel boundary) or are being overwritten with roots by this one -- either value is an ancestor.
+__device__ __forceinline__ int q_find(const int* L, int i) {
+  int p;
+  while ((p = L[i]) != i) i = p;
+  return i;
+}
+
+__global__ __launch_bounds__(CCL_BLK) void ccl_compress_kernel(int hw, int* parent) {
   const int p = blockIdx.x * CCL_BLK + threadIdx.x;
   if (p >= hw) return;
   int* L = parent + (size_t)blockIdx.y * hw;
-  if (g_load(L, p) >= 0) L[p] = g_find(L, p);
+  const int v = L[p];
+  if (v >= 0 && v != p) L[p] = q_find(L, v);
 }
 
 __global__ __launch_bounds__(CCL_BLK) void ccl_merge_kernel(const int32_t* __restrict__ labels, int64_t lstride, int h, int w, int C,
-                                                            int conn8, int* __restrict__ parent) {
+                                                            int conn8, int* parent) {
   const int hw = h * w, p = blockIdx.x * CCL_BLK + threadIdx.x;
   if (p >= hw) return;
   const int32_t* lab = labels + blockIdx.y * lstride;
@@ -140,7 +125,13 @@ __global__ __launch_bounds__(CCL_BLK) void ccl_merge_kernel(const int32_t* __res
   const int c = cls_of(lab[p], C);
   if (c < 0) return;
   const int y = p / w, x = p - y * w;
-  owed_unions(neighbours(lab, p, x, y, w, c, conn8), p, w, conn8, [&](int q) { g_unite(L, p, q); });
+  // After the compress launch nearly every pixel already shares its root with the neighbours it owes a union: one plain
+  // (L2-cached) look at both parents settles those.  The values may be stale by now, but "equal => same set" stays true
+  // because sets only ever merge.  Only the rest pays for agent-scope finds and atomics.
+  const int rp = L[p];
+  owed_unions(neighbours(lab, p, x, y, w, c, conn8), p, w, conn8, [&](int q) {
+    if (L[q] != rp) g_unite(L, p, q);
+  });
 }
 
 // Rank of a root pixel among the roots of its class inside a group of NWV waves (raster order), and the group's count
@@ -162,7 +153,7 @@ __device__ __forceinline__ int class_rank(bool is_root, int c, int C, int (*wcnt
 }
 
 __global__ __launch_bounds__(CCL_BLK) void ccl_compress_count_kernel(const int32_t* __restrict__ labels, int64_t lstride, int hw, int C,
-                                                                     int nblk, int* __restrict__ parent, int* __restrict__ lrank,
+                                                                     int nblk, int* parent, int* __restrict__ lrank,
                                                                      int* __restrict__ blockcnt) {
   __shared__ int wcnt[CCL_BLK / 64][DIGA_NUM_CLASSES_MAX];
   const int p = blockIdx.x * CCL_BLK + threadIdx.x;
@@ -173,7 +164,7 @@ __global__ __launch_bounds__(CCL_BLK) void ccl_compress_count_kernel(const int32
   if (p < hw) {
     c = cls_of(lab[p], C);
     if (c >= 0) {
-      const int r = g_find(L, p);
+      const int r = q_find(L, p);
       L[p] = r;
       is_root = r == p;
     }
@@ -198,19 +189,28 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
   return v;
 }
 
-// one wave per (class, sample): exclusive scan of the per-block root counts over the blocks
-__global__ __launch_bounds__(64) void ccl_scan_kernel(const int* __restrict__ blockcnt, int nblk, int C, int* __restrict__ blockbase,
-                                                      int32_t* __restrict__ ncomp) {
-  const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-  int run = 0;
-  for (int i0 = 0; i0 < nblk; i0 += 64) {
-    const int i = i0 + lane;
-    const int v = i < nblk ? blockcnt[((size_t)b * nblk + i) * C + c] : 0;
-    const int inc = wave_inclusive_scan(v);
-    if (i < nblk) blockbase[((size_t)b * nblk + i) * C + c] = run + inc - v;
-    run += __shfl(inc, 63);
+// one block per (class, sample): exclusive scan of the per-block root counts over the blocks.  Thread t owns the
+// contiguous segment [t*seg, (t+1)*seg) of blocks: segment sums, a block-wide scan of those, then the running prefix.
+__global__ __launch_bounds__(256) void ccl_scan_kernel(const int* __restrict__ blockcnt, int nblk, int C, int* __restrict__ blockbase,
+                                                       int32_t* __restrict__ ncomp) {
+  __shared__ int wsum[4];
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seg = (nblk + 255) / 256;
+  const int i0 = min(tid * seg, nblk), i1 = min(i0 + seg, nblk);
+  const int* src = blockcnt + (size_t)b * nblk * C + c;
+  int* dst = blockbase + (size_t)b * nblk * C + c;
+  int mine = 0;
+  for (int i = i0; i < i1; ++i) mine += src[(size_t)i * C];
+  const int inc = wave_inclusive_scan(mine);
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int run = inc - mine;
+  for (int v = 0; v < wave; ++v) run += wsum[v];
+  for (int i = i0; i < i1; ++i) {
+    dst[(size_t)i * C] = run;
+    run += src[(size_t)i * C];
   }
-  if (lane == 0) ncomp[b * C + c] = run;
+  if (tid == 255) ncomp[b * C + c] = run;
 }
 
 __global__ __launch_bounds__(CCL_BLK) void ccl_gather_kernel(const int32_t* __restrict__ labels, int64_t lstride, int hw, int C,
@@ -226,73 +226,6 @@ __global__ __launch_bounds__(CCL_BLK) void ccl_gather_kernel(const int32_t* __re
     v = blockbase[((size_t)b * nblk + r / CCL_BLK) * C + c] + lrank[(size_t)b * hw + r] + 1;
   }
   inst[(size_t)b * hw + p] = v;
-}
-
-// ---- one launch, one block per sample: the parent array lives in LDS
-__global__ __launch_bounds__(CCL_LDS_THREADS) void ccl_lds_kernel(const int32_t* __restrict__ labels, int64_t lstride, int h, int w,
-                                                                  int C, int conn8, int32_t* __restrict__ inst,
-                                                                  int32_t* __restrict__ ncomp) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NWV = CCL_LDS_THREADS / 64;
-  int* L = reinterpret_cast<int*>(smem);                                            // [hw]
-  const int hw = h * w;
-  int(*wcnt)[DIGA_NUM_CLASSES_MAX] = reinterpret_cast<int(*)[DIGA_NUM_CLASSES_MAX]>(L + ((hw + 3) & ~3));   // [NWV][32]
-  int* cbase = reinterpret_cast<int*>(wcnt + NWV);                                  // [32] running count per class
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int32_t* lab = labels + b * lstride;
-  for (int p = tid; p < hw; p += CCL_LDS_THREADS) {
-    const int c = cls_of(lab[p], C);
-    int v = -1;
-    if (c >= 0) {
-      const int y = p / w, x = p - y * w;
-      v = first_parent(neighbours(lab, p, x, y, w, c, conn8), p, w);
-    }
-    L[p] = v;
-  }
-  if (tid < DIGA_NUM_CLASSES_MAX) cbase[tid] = 0;
-  __syncthreads();
-  for (int p = tid; p < hw; p += CCL_LDS_THREADS)
-    if (L[p] >= 0) L[p] = s_find(L, p);     // a concurrent reader sees the old parent or the root: both are ancestors
-  __syncthreads();
-  for (int p = tid; p < hw; p += CCL_LDS_THREADS) {
-    const int c = cls_of(lab[p], C);
-    if (c < 0) continue;
-    const int y = p / w, x = p - y * w;
-    owed_unions(neighbours(lab, p, x, y, w, c, conn8), p, w, conn8, [&](int q) { s_unite(L, p, q); });
-  }
-  __syncthreads();
-  for (int p = tid; p < hw; p += CCL_LDS_THREADS)
-    if (L[p] >= 0) L[p] = s_find(L, p);
-  __syncthreads();
-  // number the roots chunk by chunk in raster order; a root's slot then holds -(number + 1)
-  for (int p0 = 0; p0 < hw; p0 += CCL_LDS_THREADS) {
-    const int p = p0 + tid;
-    int c = -1;
-    bool is_root = false;
-    if (p < hw) {
-      c = cls_of(lab[p], C);
-      is_root = c >= 0 && L[p] == p;
-    }
-    const int rank = class_rank<NWV>(is_root, c, C, wcnt);
-    int number = 0;
-    if (is_root) number = cbase[c] + rank + 1;
-    __syncthreads();                       // every thread has read cbase and wcnt
-    if (tid < C) {
-      int t = 0;
-      for (int v = 0; v < NWV; ++v) t += wcnt[v][tid];
-      cbase[tid] += t;
-    }
-    if (is_root) L[p] = -(number + 1);     // roots are only read through their members after the loop
-    __syncthreads();
-  }
-  for (int p = tid; p < hw; p += CCL_LDS_THREADS) {
-    const int r = L[p];
-    int v = 0;
-    if (r < -1) v = -r - 1;                // a numbered root
-    else if (r >= 0) v = -L[r] - 1;        // a member: its root's number
-    inst[(size_t)b * hw + p] = v;
-  }
-  if (tid < C) ncomp[b * C + tid] = cbase[tid];
 }
 
 struct CclPlan {
@@ -343,23 +276,35 @@ __global__ __launch_bounds__(256) void inst_key_kernel(const int32_t* __restrict
                                                        int* __restrict__ key, int* __restrict__ cnt, int* __restrict__ first,
                                                        int* __restrict__ last) {
   const int64_t pg = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (pg >= P) return;
-  const int b = (int)(pg / hw);
-  const int64_t p = pg - (int64_t)b * hw;
-  const int c = cls_of(labels[b * lstride + p], C);
-  const int i = inst[pg];
+  const int lane = threadIdx.x & 63;
   int g = -1;
-  if (c >= 0 && i > 0) {
-    g = base[b * C + c] + i - 1;
-    if (g < max_inst) {
-      atomicAdd(cnt + g, 1);            // integer atomics: the results do not depend on their order
-      atomicMin(first + g, (int)pg);
-      atomicMax(last + g, (int)pg);
-    } else {
-      g = -1;                           // beyond the caller's table: dropped (n_total tells)
+  if (pg < P) {
+    const int b = (int)(pg / hw);
+    const int64_t p = pg - (int64_t)b * hw;
+    const int c = cls_of(labels[b * lstride + p], C);
+    const int i = inst[pg];
+    if (c >= 0 && i > 0) {
+      g = base[b * C + c] + i - 1;
+      if (g >= max_inst) g = -1;          // beyond the caller's table: dropped (n_total tells)
     }
+    key[pg] = g;
   }
-  key[pg] = g;
+  // One set of atomics per (wave, instance) instead of per pixel: neighbouring pixels mostly share their instance, and a
+  // large component would otherwise serialise thousands of updates of the same three words.  Lanes are in pixel order,
+  // so the lowest / highest lane of a group holds its first / last pixel.  Integer atomics: order does not matter.
+  unsigned long long todo = __ballot(g >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int g0 = __shfl(g, leader);
+    const unsigned long long m = __ballot(g == g0);
+    if (lane == leader) {
+      const int lo = (int)(pg - lane) + leader, hi = (int)(pg - lane) + 63 - __clzll((long long)m);
+      atomicAdd(cnt + g0, __popcll(m));
+      atomicMin(first + g0, lo);
+      atomicMax(last + g0, hi);
+    }
+    todo &= ~m;
+  }
 }
 
 // single block: offs = exclusive scan of cnt, joffs = exclusive scan of the job counts ceil(cnt / IP_CS)
@@ -425,7 +370,7 @@ __global__ __launch_bounds__(64) void inst_list_kernel(const int* __restrict__ b
 __global__ __launch_bounds__(256) void inst_pool_kernel(const unsigned short* __restrict__ feat, const int* __restrict__ base, int BC,
                                                         int max_inst, const int* __restrict__ cnt, const int* __restrict__ offs,
                                                         const int* __restrict__ joffs, const int* __restrict__ list, int CH,
-                                                        float* __restrict__ partial) {
+                                                        float* __restrict__ partial, float* __restrict__ protos) {
   const int j = blockIdx.x;
   const int n = min(base[BC], max_inst);
   if (j >= joffs[n]) return;
@@ -437,8 +382,12 @@ __global__ __launch_bounds__(256) void inst_pool_kernel(const unsigned short* __
   }
   const int g = lo;
   const int beg = offs[g] + (j - joffs[g]) * IP_CS;
-  const int end = min(beg + IP_CS, offs[g] + cnt[g]);
-  float* dst = partial + (size_t)j * CH;
+  const int nc = cnt[g];
+  const int end = min(beg + IP_CS, offs[g] + nc);
+  // an instance of a single job (most are small) is finished here: its mean goes straight to the table
+  const bool whole = joffs[g + 1] - joffs[g] == 1;
+  float* dst = whole ? protos + (size_t)g * CH : partial + (size_t)j * CH;
+  const float div = whole ? (float)nc : 1.f;
   for (int ch0 = threadIdx.x * 8; ch0 < CH; ch0 += 2048) {
     float acc[8];
 #pragma unroll
@@ -462,19 +411,20 @@ __global__ __launch_bounds__(256) void inst_pool_kernel(const unsigned short* __
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] += f[i];
     }
-    *reinterpret_cast<f32x4*>(dst + ch0) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-    *reinterpret_cast<f32x4*>(dst + ch0 + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    *reinterpret_cast<f32x4*>(dst + ch0) = f32x4{acc[0] / div, acc[1] / div, acc[2] / div, acc[3] / div};
+    *reinterpret_cast<f32x4*>(dst + ch0 + 4) = f32x4{acc[4] / div, acc[5] / div, acc[6] / div, acc[7] / div};
   }
 }
 
+// one block per table row: the row's meta data, and for instances of several pooling jobs the fixed-order sum of their partials
 __global__ __launch_bounds__(256) void inst_reduce_kernel(const float* __restrict__ partial, const int* __restrict__ base, int BC, int C,
                                                           int max_inst, const int* __restrict__ cnt, const int* __restrict__ joffs,
                                                           int CH, float* __restrict__ protos, int32_t* __restrict__ counts,
                                                           int32_t* __restrict__ inst_class, int32_t* __restrict__ inst_sample) {
-  const int g = blockIdx.y;
+  const int g = blockIdx.x;
   const int n = min(base[BC], max_inst);
   if (g >= n) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (threadIdx.x == 0) {
       counts[g] = 0;
       inst_class[g] = -1;
       inst_sample[g] = -1;
@@ -482,8 +432,8 @@ __global__ __launch_bounds__(256) void inst_reduce_kernel(const float* __restric
     return;
   }
   const int nc = cnt[g];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    int lo = 0, hi = BC - 1;              // largest (b, c) with base <= g and a component there
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = BC - 1;              // largest (b, c) with base <= g: the one whose components include row g
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
       if (base[mid] <= g) lo = mid;
@@ -493,12 +443,13 @@ __global__ __launch_bounds__(256) void inst_reduce_kernel(const float* __restric
     inst_class[g] = lo % C;
     inst_sample[g] = lo / C;
   }
-  const int ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch >= CH) return;
   const int j0 = joffs[g], j1 = joffs[g + 1];
-  float v = 0.f;
-  for (int j = j0; j < j1; ++j) v += partial[(size_t)j * CH + ch];
-  protos[(size_t)g * CH + ch] = v / (float)nc;
+  if (j1 - j0 == 1) return;               // written by its only pooling job
+  for (int ch = threadIdx.x; ch < CH; ch += 256) {
+    float v = 0.f;
+    for (int j = j0; j < j1; ++j) v += partial[(size_t)j * CH + ch];
+    protos[(size_t)g * CH + ch] = v / (float)nc;
+  }
 }
 
 struct InstPlan {
@@ -533,7 +484,7 @@ extern "C" int64_t diga_ccl_work_bytes(int B, int h, int w, int C) {
 }
 
 extern "C" int diga_ccl_label(const int32_t* labels, int64_t label_sample_stride, int B, int h, int w, int C, int connectivity,
-                              int32_t* inst, int32_t* ncomp, void* work, int force_global, void* stream) {
+                              int32_t* inst, int32_t* ncomp, void* work, void* stream) {
   DIGA_CHECK_ARG(labels && inst && ncomp && work, "diga_ccl_label: NULL pointer");
   DIGA_CHECK_ARG(B > 0 && h > 0 && w > 0 && (int64_t)h * w < (1ll << 31) && (int64_t)B * h * w < (1ll << 40), "diga_ccl_label: bad sizes");
   DIGA_CHECK_ARG(C > 0 && C <= DIGA_NUM_CLASSES_MAX, "diga_ccl_label: C=%d outside 1..%d", C, DIGA_NUM_CLASSES_MAX);
@@ -543,18 +494,6 @@ extern "C" int diga_ccl_label(const int32_t* labels, int64_t label_sample_stride
   DIGA_CHECK_ARG(ls >= hw, "diga_ccl_label: label_sample_stride < h*w");
   const int conn8 = connectivity == 8;
   hipStream_t st = (hipStream_t)stream;
-  if (hw <= CCL_LDS_MAX && !force_global) {
-    const int smem = ((hw + 3) & ~3) * 4 + (CCL_LDS_THREADS / 64 + 1) * DIGA_NUM_CLASSES_MAX * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ccl_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                CCL_LDS_MAX * 4 + (CCL_LDS_THREADS / 64 + 1) * DIGA_NUM_CLASSES_MAX * 4);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(ccl_lds_kernel, dim3(B), dim3(CCL_LDS_THREADS), smem, st, labels, ls, h, w, C, conn8, inst, ncomp);
-    DIGA_CHECK_LAUNCH("diga_ccl_label");
-    return DIGA_OK;
-  }
   const CclPlan pl = ccl_plan(B, h, w, C);
   int* parent = (int*)work;
   int* lrank = (int*)((char*)work + pl.parent_bytes);
@@ -565,7 +504,7 @@ extern "C" int diga_ccl_label(const int32_t* labels, int64_t label_sample_stride
   hipLaunchKernelGGL(ccl_compress_kernel, grid, block, 0, st, hw, parent);
   hipLaunchKernelGGL(ccl_merge_kernel, grid, block, 0, st, labels, ls, h, w, C, conn8, parent);
   hipLaunchKernelGGL(ccl_compress_count_kernel, grid, block, 0, st, labels, ls, hw, C, pl.nblk, parent, lrank, blockcnt);
-  hipLaunchKernelGGL(ccl_scan_kernel, dim3(C, B), dim3(64), 0, st, blockcnt, pl.nblk, C, blockbase, ncomp);
+  hipLaunchKernelGGL(ccl_scan_kernel, dim3(C, B), dim3(256), 0, st, blockcnt, pl.nblk, C, blockbase, ncomp);
   hipLaunchKernelGGL(ccl_gather_kernel, grid, block, 0, st, labels, ls, hw, C, pl.nblk, parent, lrank, blockbase, inst);
   DIGA_CHECK_LAUNCH("diga_ccl_label");
   return DIGA_OK;
@@ -602,8 +541,8 @@ extern "C" int diga_instance_pool(const void* feat, const int32_t* labels, int64
   hipLaunchKernelGGL(inst_scan_kernel, dim3(1), dim3(1024), 0, st, base, BC, max_inst, cnt, offs, joffs);
   hipLaunchKernelGGL(inst_list_kernel, dim3(max_inst), dim3(64), 0, st, base, BC, max_inst, key, first, last, offs, list);
   hipLaunchKernelGGL(inst_pool_kernel, dim3(pl.max_jobs), dim3(256), 0, st, (const unsigned short*)feat, base, BC, max_inst, cnt, offs,
-                     joffs, list, CH, partial);
-  hipLaunchKernelGGL(inst_reduce_kernel, dim3(cdiv(CH, 256), max_inst), dim3(256), 0, st, partial, base, BC, C, max_inst, cnt, joffs, CH,
+                     joffs, list, CH, partial, protos);
+  hipLaunchKernelGGL(inst_reduce_kernel, dim3(max_inst), dim3(256), 0, st, partial, base, BC, C, max_inst, cnt, joffs, CH,
                      protos, counts, inst_class, inst_sample);
   DIGA_CHECK_LAUNCH("diga_instance_pool");
   return DIGA_OK;

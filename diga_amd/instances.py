@@ -37,7 +37,7 @@ def _labels_i32(labels: torch.Tensor) -> torch.Tensor:
     return labels.to(torch.int32).contiguous()
 
 
-def ccl_label(labels: torch.Tensor, num_classes: int = 19, connectivity: int = 8, force_global: bool = False):
+def ccl_label(labels: torch.Tensor, num_classes: int = 19, connectivity: int = 8):
     """labels: integer [B,h,w] (or [h,w]) on the device, values outside [0, num_classes) are background.
     -> (inst int32 [B,h,w], ncomp int32 [B,num_classes])."""
     lab = _labels_i32(labels)
@@ -46,7 +46,7 @@ def ccl_label(labels: torch.Tensor, num_classes: int = 19, connectivity: int = 8
     work = torch.empty(nbytes, dtype=torch.uint8, device=lab.device)
     inst = torch.empty(B, h, w, dtype=torch.int32, device=lab.device)
     ncomp = torch.empty(B, num_classes, dtype=torch.int32, device=lab.device)
-    call("diga_ccl_label", _p(lab), 0, B, h, w, num_classes, connectivity, _p(inst), _p(ncomp), _p(work), int(force_global), _stream())
+    call("diga_ccl_label", _p(lab), 0, B, h, w, num_classes, connectivity, _p(inst), _p(ncomp), _p(work), _stream())
     return inst, ncomp
 
 

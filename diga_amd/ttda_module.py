@@ -535,6 +535,25 @@ class DIGA(nn.Module):
              _p(torch.zeros(1, dtype=torch.int32, device=self.device)), 1.0, 0.0, _stream())
         return inst, iflag
 
+    # ---- optional extension, NOT part of the reference's DIGA and not called by forward_and_adapt
+    def instance_labels(self, y, connectivity: int = 8):
+        """Connected components of the per-class masks of a label map y [B,h,w] (e.g. the pseudo-labels of
+        high_confident_proto_label) -> (inst int64 [B,h,w]: 0 = background / ignore, else the component's number inside
+        its class, from 1 in raster order; ncomp int64 [B,C])."""
+        from . import instances
+        inst, ncomp = instances.ccl_label(y.to(self.device), self.hparams.dataset_info["num_classes"], connectivity)
+        return inst.long(), ncomp.long()
+
+    def cal_instance_proto(self, feature, y, connectivity: int = 8, max_instances: int = 4096):
+        """cal_proto per connected component instead of per class: feature [B,CH,h,w], y [B,h,w] ->
+        instances.InstanceTable (protos [N,CH], counts, classes, samples, total), rows in (sample, class, number) order."""
+        from . import instances
+        Cn = self.hparams.dataset_info["num_classes"]
+        B, CH, h, w = feature.shape
+        labs = y.to(self.device).reshape(B, h, w)
+        inst, ncomp = instances.ccl_label(labs, Cn, connectivity)
+        return instances.instance_prototypes(self._feat_nhwc(feature).reshape(B * h * w, CH), labs, inst, ncomp, Cn, max_instances)
+
     def cal_pred_of_proto(self, feature, proto, exists_flag, tau=1.0):
         """ttda:1712-1734 -> weight [B,C,H,W] (NaN where no class exists / all underflow)."""
         B, CH, h, w = feature.shape

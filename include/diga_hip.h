@@ -212,13 +212,10 @@ int diga_proto_classify_fuse(const void* feat, const float* logits, const float*
  * connectivity: 4 or 8.
  * inst: int32 [B][h*w]: 0 = background, else the number of the pixel's component inside ITS class's mask, counted
  *   from 1 in raster order of the components' first pixels  (== scipy.ndimage.label(labels[b] == c, structure)).
- * ncomp: int32 [B][C] components per class.  work: diga_ccl_work_bytes() bytes of scratch.
- * Frames of up to 36 864 pixels (every feature grid of the net) run in one launch on an LDS-resident parent
- * array, larger ones through global memory; force_global != 0 takes the second path regardless (tests). */
+ * ncomp: int32 [B][C] components per class.  work: diga_ccl_work_bytes() bytes of scratch. */
 int64_t diga_ccl_work_bytes(int B, int h, int w, int C);
 int diga_ccl_label(const int32_t* labels, int64_t label_sample_stride, int B, int h, int w, int C,
-                   int connectivity, int32_t* inst, int32_t* ncomp, void* work, int force_global,
-                   void* stream);
+                   int connectivity, int32_t* inst, int32_t* ncomp, void* work, void* stream);
 
 /* Instance-masked prototype pooling: the mean feature row of every component found by diga_ccl_label.
  * feat: bf16 [B*hw][CH] (CH % 8 == 0); labels / inst / ncomp as above.  Row g of the instance table is component

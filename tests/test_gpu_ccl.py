@@ -14,13 +14,12 @@ pytestmark = pytest.mark.gpu
 CASES = ("tiny", "feat", "noisy", "wide", "shapes")
 
 
-@pytest.mark.parametrize("force_global", [False, True])
-def test_ccl_matches_scipy_fixture(gold_ccl, force_global):
+def test_ccl_matches_scipy_fixture(gold_ccl):
     g = gold_ccl
     for tag in CASES:
         lab = torch.from_numpy(g[f"{tag}_labels"]).cuda()
         for conn in (4, 8):
-            inst, ncomp = instances.ccl_label(lab, int(g[f"{tag}_C"]), conn, force_global=force_global)
+            inst, ncomp = instances.ccl_label(lab, int(g[f"{tag}_C"]), conn)
             assert np.array_equal(ncomp.cpu().numpy(), g[f"{tag}_ncomp{conn}"]), (tag, conn)
             assert np.array_equal(inst.cpu().numpy(), g[f"{tag}_inst{conn}"]), (tag, conn)
 
@@ -37,16 +36,14 @@ def _labels(rng, B, h, w, C, cell, noise, ignore):
 @pytest.mark.parametrize("shape", [(3, 129, 257, 19, 16, 0.05), (1, 512, 1024, 19, 40, 0.01), (2, 1, 700, 5, 7, 0.1), (2, 300, 1, 5, 7, 0.1),
                                    (1, 192, 192, 2, 1, 0.0)])
 def test_ccl_matches_oracle_at_frame_sizes(shape):
-    """Feature-grid frames take the one-launch LDS path, the 512x1024 label map the global path; both are also forced
-    through the global path and must agree.  Single-row / single-column frames and pure noise (cell 1) included."""
+    """Feature grids, a full-resolution label map, single-row / single-column frames and pure noise (cell 1)."""
     B, h, w, Cn, cell, noise = shape
     lab = _labels(np.random.default_rng(h * 7 + w), B, h, w, Cn, cell, noise, 0.04)
     for conn in (4, 8):
         want_inst, want_n = O.ccl_label(lab, Cn, conn)
-        for force in (False, True):
-            inst, ncomp = instances.ccl_label(torch.from_numpy(lab).cuda(), Cn, conn, force_global=force)
-            assert np.array_equal(ncomp.cpu().numpy(), want_n)
-            assert np.array_equal(inst.cpu().numpy(), want_inst)
+        inst, ncomp = instances.ccl_label(torch.from_numpy(lab).cuda(), Cn, conn)
+        assert np.array_equal(ncomp.cpu().numpy(), want_n)
+        assert np.array_equal(inst.cpu().numpy(), want_inst)
 
 
 def test_ccl_edge_cases():
@@ -61,9 +58,8 @@ def test_ccl_edge_cases():
     lab[0, ::2, :] = 3
     lab[0, 1::4, w - 1] = 3
     lab[0, 3::4, 0] = 3                       # one snake through every even row
-    for force in (False, True):
-        inst, ncomp = instances.ccl_label(torch.from_numpy(lab).cuda(), 19, 4, force_global=force)
-        assert int(ncomp[0, 3]) == 1 and np.array_equal(inst.cpu().numpy()[0] > 0, lab[0] == 3)
+    inst, ncomp = instances.ccl_label(torch.from_numpy(lab).cuda(), 19, 4)
+    assert int(ncomp[0, 3]) == 1 and np.array_equal(inst.cpu().numpy()[0] > 0, lab[0] == 3)
     with pytest.raises(DigaError):
         instances.ccl_label(torch.zeros(1, 4, 4, dtype=torch.int32), 19, 8)            # CPU tensor: no fallback
     with pytest.raises(DigaError):
@@ -98,3 +94,25 @@ def test_instance_pool_matches_oracle(case):
     small = instances.instance_prototypes(f_nhwc, labd, inst, ncomp, Cn, max_instances=7)
     assert small.total == t.total and small.protos.shape[0] == 7 and torch.equal(small.protos, t.protos[:7])
     assert torch.equal(small.counts, t.counts[:7])
+
+
+def test_module_level_api():
+    """DIGA.instance_labels / DIGA.cal_instance_proto (optional extension of the module mirror) on NCHW fp32 tensors."""
+    import functools
+
+    from diga_amd.ttda_module import DIGA, DeepLabv2AdaptSeg
+    names = [f"c{i}" for i in range(19)]
+    m = DIGA(net=functools.partial(DeepLabv2AdaptSeg, multi_level=True, restore_from=None),
+             dataset_info=dict(num_classes=19, image_size=(64, 64), test_list=[0], class_names=names),
+             cfg=dict(bn_lambda=0.8, proto_lambda=0.8, fusion_lambda=0.8, confidence_threshold=0.9, proto_rho=0.1)).cuda().eval()
+    rng = np.random.default_rng(4)
+    lab = _labels(rng, 2, 17, 33, 19, 5, 0.1, 0.05)
+    feat = torch.from_numpy(rng.standard_normal((2, 64, 17, 33)).astype(np.float32))
+    inst, ncomp = m.instance_labels(torch.from_numpy(lab).long())
+    want_inst, want_n = O.ccl_label(lab, 19, 8)
+    assert inst.dtype == torch.int64 and np.array_equal(inst.cpu().numpy(), want_inst) and np.array_equal(ncomp.cpu().numpy(), want_n)
+    t = m.cal_instance_proto(feat, torch.from_numpy(lab).long())
+    protos, counts, cls, smp = O.instance_prototypes(feat.to(torch.bfloat16).float().numpy(), lab, want_inst, want_n, 19)
+    assert t.total == len(counts) and np.array_equal(t.counts.cpu().numpy(), counts) and np.array_equal(t.classes.cpu().numpy(), cls)
+    scale = np.maximum(np.abs(protos).max(axis=1, keepdims=True), 1e-6)
+    assert float((np.abs(t.protos.cpu().numpy() - protos) / scale).max()) < 1e-3
