@@ -141,7 +141,7 @@ class Engine:
 
     def __init__(self, weights: NetWeights, B: int, H: int, W: int, bn_lambda: float = 0.8, group=None,
                  confidence_threshold: float = 0.9, stream: bool = False, conv_tile: int = 0,
-                 autotune: bool = False, fuse_conv3: bool = False):
+                 autotune: bool = False, fuse_conv3: bool = False, force_exchange: bool = False):
         """stream=False: x is ONE batch of B samples -> the reference's batch semantics (half_first DAM statistics over
         the batch, prototypes pooled over the batch).  stream=True: x holds B CONSECUTIVE batch-1 frames of a stream
         ("frames in flight"): the trunk runs once over all of them with per-sample DAM statistics (DAM carries no
@@ -175,6 +175,9 @@ class Engine:
             self.rank = dist.get_rank(group)
         else:
             self.world, self.rank = 1, 0
+        # the statistics / prototype exchange runs whenever there is more than one rank; force_exchange takes the same
+        # code path with a single-rank group (how the RCCL calls are exercised on a one-GPU box, tests/test_gpu_dist.py)
+        self.exchange = self.world > 1 or (bool(force_exchange) and group is not None)
         (self.h1, self.w1), (self.h2, self.w2), (self.h3, self.w3) = feature_grid(H, W)
         self.h, self.wd = self.h3, self.w3
         self.hw = self.h * self.wd
@@ -256,7 +259,7 @@ class Engine:
     def _finalize(self, bn: BNP, ups, rows_per_sample):
         """slab (this rank's B samples x ups units) -> scale/shift of one BN layer."""
         sc, sh = self._affine(bn)
-        if self.stream and self.world == 1:
+        if self.stream and not self.exchange:
             call("diga_bn_finalize", _p(self.slab), ups, self.B, self.B, 1, bn.C, float(rows_per_sample), 0.0,
                  _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
             return sc, sh
@@ -270,7 +273,7 @@ class Engine:
             return sc, sh
         split, n_a, n_b = self._groups(rows_per_sample)
         a_samples = split // rows_per_sample
-        if self.world > 1:
+        if self.exchange:
             sums = self.sums[:4 * bn.C]
             call("diga_bn_reduce_slab", _p(self.slab), ups, self.B, a_samples, 0, bn.C, _p(sums), _stream())
             self._all_reduce(sums)
@@ -478,7 +481,7 @@ class Engine:
             labels = self.labels[s * 2 * hw:] if self.stream else self.labels
             call("diga_proto_pool", _p(feat), _p(labels), 2, Ps, Cn, FEAT_CH, _p(self.pool_work), _p(self.pool_sums[s * SC:]),
                  _p(self.pool_counts[s * 2 * Cn:]), _stream())
-        if self.world > 1:
+        if self.exchange:
             self._all_reduce(self.pool_sums)
             self._all_reduce(self.pool_counts)
         for s in range(nset):

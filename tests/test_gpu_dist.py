@@ -138,3 +138,60 @@ def test_two_ranks_reproduce_batch2_semantics():
         assert np.array_equal(res[0][t]["run"], res[1][t]["run"])
         ref_run = eng.run_proto.cpu().numpy()
         assert np.abs(res[0][t]["run"] - ref_run).max() <= 1e-5 * np.abs(ref_run).max()
+
+
+def _rccl_worker(port, q):
+    """One rank, backend "nccl" (= RCCL): the exchange code path of the sharded engine (fp64 BN sums, fp32 prototype sums,
+    int32 counts all-reduced on the device, in stream order with the kernels) must reproduce the engine without a group."""
+    import time
+    import traceback
+
+    import torch.distributed as dist
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    os.makedirs("gpurun_out", exist_ok=True)
+    log = open("gpurun_out/dist_rccl1.log", "w")
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        w = NetWeights(synth.synth_params(0), dev)
+        ok = True
+        for stream_mode in (False, True):
+            a = Engine(w, 2, H, W, group=dist.group.WORLD, stream=stream_mode, force_exchange=True)
+            b = Engine(w, 2, H, W, stream=stream_mode)
+            assert a.exchange and not b.exchange
+            for t in range(2):
+                x, y = synth.synth_frame(t, 2, H, W)
+                x, y = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+                pa, pb = a.forward_and_adapt(x, y, CFG), b.forward_and_adapt(x, y, CFG)
+                a.tail(y), b.tail(y)
+                torch.cuda.synchronize()
+                same = (torch.equal(a.scale, b.scale) and torch.equal(a.logits, b.logits) and torch.equal(a.run_proto, b.run_proto)
+                        and torch.equal(a.hist, b.hist) and torch.equal(torch.nan_to_num(pa, nan=-1.0), torch.nan_to_num(pb, nan=-1.0)))
+                print("stream" if stream_mode else "batch", "frame", t, "bit-identical" if same else "DIFFERENT", file=log, flush=True)
+                ok = ok and same
+            t0 = time.perf_counter()
+            for _ in range(3):
+                a.forward_and_adapt(x, y, CFG)
+            torch.cuda.synchronize()
+            print(f"eager step with 104 + 2 RCCL all-reduces: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", file=log, flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(ok)
+    except Exception:
+        traceback.print_exc(file=log)
+        log.flush()
+        q.put(None)
+        raise
+
+
+def test_rccl_single_rank_group_takes_the_exchange_path():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29600 + (os.getpid() + 31) % 2000, q))
+    p.start()
+    ok = q.get(timeout=100)
+    p.join(timeout=60)
+    assert ok is True, "see gpurun_out/dist_rccl1.log"
