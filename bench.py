@@ -110,6 +110,54 @@ def cpu_baseline(nframes_timed=10, H=512, W=1024):
                        f"confusion matrix), torch {torch.__version__} CPU")
 
 
+def miou_vs_reference(weights, dev, fif, nwin, autotune):
+    """The "mIoU delta vs ref" half of BASELINE.json's metric: the first frames of the synthetic batch-1 stream through the
+    SAME configuration the throughput is measured in (nwin windows of fif frames in flight), fresh prototypes, against the
+    reference's own mIoU-19/16/13 for those frames (tests/golden/net_stream.npz, written by oracle/gen_golden.py from the
+    reference source on CPU).  Bar: +-0.1 (north star)."""
+    from diga_amd import synth
+    from diga_amd.pipeline import StreamWindows
+    from diga_amd.ttda_module import SegmentationMetric
+    path = os.path.join(ROOT, "tests", "golden", "net_stream.npz")
+    if not os.path.exists(path):
+        return None
+    with np.load(path, allow_pickle=False) as z:
+        ref = [float(v) for v in z["st_miou"]]
+        nframes = int(z["st_frames"])
+        ref_hist = z[f"st_{nframes - 1}_hist"]
+    k = min(fif, nframes)
+    nw = nwin if k * nwin <= nframes else 1
+    H, W = 512, 1024
+    sw = StreamWindows(weights, k, nw, H, W, bn_lambda=CFG["bn_lambda"], autotune=autotune)
+    t = 0
+    while t < nframes:                     # whole steps first, the remainder through one-window engines of the right size
+        per_step = k * nw
+        if t + per_step > nframes:
+            hist, run = sw.engines[0].hist, (sw.engines[0].run_proto, sw.engines[0].run_flag, sw.engines[0].state_flag)
+            k, nw = nframes - t, 1
+            sw = StreamWindows(weights, k, 1, H, W, bn_lambda=CFG["bn_lambda"], autotune=False)
+            e = sw.engines[0]
+            e.hist, (e.run_proto, e.run_flag, e.state_flag) = hist, run
+            per_step = k
+        wins = []
+        for w in range(nw):
+            xy = [synth.synth_frame(t + w * k + j, 1, H, W) for j in range(k)]
+            wins.append((torch.from_numpy(np.concatenate([a for a, _ in xy])).to(dev),
+                         torch.from_numpy(np.concatenate([b for _, b in xy])).to(dev)))
+        sw.step(wins, CFG)
+        t += per_step
+    torch.cuda.synchronize()
+    m = SegmentationMetric(19)
+    hist = sw.engines[0].hist.reshape(19, 19).cpu()
+    m.add_counts(hist)
+    got = [float(m.compute()), float(m.compute_iou("16")), float(m.compute_iou("13"))]
+    return {"frames": nframes, "miou19_16_13": [round(v, 4) for v in got], "reference": [round(v, 4) for v in ref],
+            "delta": [round(a - b, 4) for a, b in zip(got, ref)], "bar": 0.1,
+            "confusion_entries_differing": int((hist.numpy() != ref_hist).sum()),
+            "pixels_moved": int(np.abs(hist.numpy() - ref_hist).sum() // 2),
+            "source": "tests/golden/net_stream.npz: the reference's forward_and_adapt + Upsample + SegmentationMetric on the same frames (fp32, CPU)"}
+
+
 def run_config(args, world, rank, dev, group, weights, fif, steps, warmup, nwin=1):
     """Build the engine(s) for `nwin` windows of `fif` frames per step, time `steps` steps
     -> (fps, ms_per_step, first engine, frame windows, use_graph)."""
@@ -204,6 +252,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="skip the library-GEMM / device-copy peak check")
     ap.add_argument("--no-latency-mode", action="store_true", help="skip the extra one-frame-per-step measurement")
+    ap.add_argument("--no-miou", action="store_true", help="skip the mIoU-vs-reference leg (8 frames through the measured configuration)")
     ap.add_argument("--dump", default=None, help="write the per-conv timing table to this JSON file")
     args = ap.parse_args()
 
@@ -276,6 +325,8 @@ def main():
         f1, ms1, e1, _, _ = run_config(args, world, rank, dev, group, weights, 1, max(10, args.steps), min(args.warmup, 10))
         res["one_frame_per_step"] = {"value": round(f1, 2), "unit": "frames/s", "ms_per_step": round(ms1, 4)}
         del e1
+    if rank == 0 and world == 1 and not args.no_miou:
+        res["miou_vs_reference"] = miou_vs_reference(weights, dev, fif, nwin, not args.no_autotune)
     if rank == 0 and world == 1 and not args.no_calibration:
         res["calibration"] = calibrate(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

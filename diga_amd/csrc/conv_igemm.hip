@@ -263,12 +263,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
           const float kshift = c < p.Cout ? p.shift[c] : 0.f;
           float t1 = 0.f, t2 = 0.f;
           if (full) {
+            // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two rows per instruction -- with a short K loop (conv3: K = 256)
+            // this epilogue is a third of a tile's time and the MFMA pipe idles through it.  Even rows and odd rows are
+            // summed separately and added at the end: a fixed order, the same for every tile shape.
+            f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+            const f32x2 ks = {kshift, kshift};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float d = acc[a][b][r] - kshift;
-              t1 += d;
-              t2 = fmaf(d, d, t2);
+            for (int r = 0; r < 16; r += 2) {
+              const f32x2 x = {acc[a][b][r], acc[a][b][r + 1]};
+              const f32x2 d = x - ks;
+              p1 += d;
+              p2 = __builtin_elementwise_fma(d, d, p2);
             }
+            t1 = p1[0] + p1[1];
+            t2 = p2[0] + p2[1];
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

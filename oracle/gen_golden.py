@@ -283,6 +283,27 @@ def gen_net_multires(m):
     np.savez_compressed(os.path.join(GOLD, "net_multires.npz"), **out)
 
 
+STREAM_FRAMES = 30
+
+
+def gen_net_stream(m):
+    """BASELINE configs[1] as the bench runs it: one batch-1 stream of 1024x512 frames (frame t = synth_frame(t)), fresh
+    prototypes, the reference's forward_and_adapt + Upsample + SegmentationMetric.  Stored per frame: the cumulative
+    confusion matrix, the running-prototype flags and the prediction's class histogram; and the stream's mIoU-19/16/13 --
+    the "mIoU delta vs ref" half of BASELINE.json's metric (bench.py reports it, tests/test_gpu_net.py bounds it)."""
+    out = {}
+    frames = [synth.synth_frame(t, 1, 512, 1024) for t in range(STREAM_FRAMES)]
+    res, metric = run_sequence(m, frames)
+    for t, r in enumerate(res):
+        out[f"st_{t}_hist"] = np_(r["hist"]).astype(np.int64)
+        out[f"st_{t}_rflag"] = np_(r["rflag"])
+        out[f"st_{t}_pred_count"] = np.bincount(np_(r["pred"]).ravel(), minlength=19).astype(np.int64)
+        out[f"st_{t}_nan_pixels"] = np.int64(torch.isnan(r["probs"]).any(1).sum())
+    out["st_miou"] = np.array([float(metric.compute()), float(metric.compute_iou("16")), float(metric.compute_iou("13"))])
+    out["st_frames"] = np.int64(STREAM_FRAMES)
+    np.savez_compressed(os.path.join(GOLD, "net_stream.npz"), **out)
+
+
 def gen_loader():
     """restore(): file named *baseline* with layer5.* head keys -> model layer6.* (ttda:1000-1016)."""
     p = synth.synth_params(0)
@@ -357,8 +378,8 @@ def gen_fn_input():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["bn", "sam", "tail", "small", "full", "multires", "loader", "input"]
-    m = make_diga() if set(which) & {"sam", "tail", "small", "full", "multires"} else None
+    which = sys.argv[1:] or ["bn", "sam", "tail", "small", "full", "multires", "stream", "loader", "input"]
+    m = make_diga() if set(which) & {"sam", "tail", "small", "full", "multires", "stream"} else None
     if "bn" in which:
         gen_fn_bn()
     if "sam" in which:
@@ -371,6 +392,8 @@ if __name__ == "__main__":
         gen_net_full(m)
     if "multires" in which:
         gen_net_multires(m)
+    if "stream" in which:
+        gen_net_stream(m)
     if "loader" in which:
         gen_loader()
     if "input" in which:

@@ -205,6 +205,21 @@ def test_end_to_end_vs_reference_full_res(diga, gold_full):
     assert np.abs(np.array(mious) - gold_full["miou"]).max() <= 0.1
 
 
+def test_stream_miou_vs_reference_30_frames(weights):
+    """BASELINE.json's metric, second half ("mIoU delta vs ref"): 30 frames of the batch-1 stream through the configuration
+    bench.py measures (2 windows x 15 frames in flight) and through 8 + 8 + 8 + 6 frames in one window, against the
+    reference's mIoU-19/16/13 for the same frames (tests/golden/net_stream.npz).  Bar: +-0.1."""
+    import bench
+    dev = torch.device("cuda:0")
+    a = bench.miou_vs_reference(weights, dev, 15, 2, False)
+    b = bench.miou_vs_reference(weights, dev, 8, 1, False)
+    print(a, b)
+    assert a["frames"] == 30 and max(abs(d) for d in a["delta"]) <= 0.1
+    assert a["miou19_16_13"] == b["miou19_16_13"] and a["pixels_moved"] == b["pixels_moved"]     # bit-identical whatever the windowing
+    # arg-max agreement with the fp32 reference sits at the bf16-storage floor (tests/golden/bf16_floor.json: 92-99.6 %)
+    assert a["pixels_moved"] <= 0.03 * 30 * 512 * 1024
+
+
 def test_end_to_end_multi_resolution_stream(diga):
     """BASELINE configs[4]: one stream whose frame size changes (1280x720, 1024x512, 960x540) without resetting the
     prototypes -- three engines share the one SAM state -- against the reference run of the same stream."""
