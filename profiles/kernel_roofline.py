@@ -1,6 +1,6 @@
 """Per-kernel roofline table from a rocprofv3 --kernel-trace of bench.py (profiles/collect.sh):
 algorithmic bytes / FLOPs of one step (k frames in flight, 1024x512) divided by the kernel family's time per step.
-    python profiles/kernel_roofline.py gpurun_out/prof_r1c/trace/t_kernel_trace.csv 7 > profiles/r1c_kernel_roofline.md
+    python profiles/kernel_roofline.py gpurun_out/prof_r1d/trace/t_kernel_trace.csv 7 > profiles/r1d_kernel_roofline.md
 Only steady-state steps are counted (the first 8 stem launches = eager warm-up, tile autotune and graph warm-up are skipped);
 the number of steps is the stem kernel's remaining call count (one launch per step)."""
 import csv

@@ -1,5 +1,5 @@
-"""Turn gpurun_out/prof_r1c (profiles/collect.sh) into the committed summaries:
-   profiles/r1c_bench_kernel_stats.csv   rocprofv3 --stats table of the bench command
+"""Turn gpurun_out/prof_r1d (profiles/collect.sh) into the committed summaries:
+   profiles/r1d_bench_kernel_stats.csv   rocprofv3 --stats table of the bench command
    profiles/conv_traffic.json            HBM-side bytes of the igemm launches of ONE step, from the PMC passes:
                                          (2 x FETCH_SIZE + WRITE_SIZE) x 1024  (MI355X_MICROARCH.md, HBM: on gfx950
                                          FETCH_SIZE tallies the 128-byte requests of 16-B/lane streams at 64 B -> x2;
@@ -11,12 +11,12 @@ import os
 import shutil
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r1c"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r1d"
 fif = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 here = os.path.dirname(os.path.abspath(__file__))
-shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(here, "r1c_bench_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(here, "r1d_bench_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "trace2", "t_kernel_stats.csv")):      # default command: two windows, kernels overlap
-    shutil.copy(os.path.join(src, "trace2", "t_kernel_stats.csv"), os.path.join(here, "r1c_bench_2windows_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "trace2", "t_kernel_stats.csv"), os.path.join(here, "r1d_bench_2windows_kernel_stats.csv"))
 
 
 def last_step(path, counter, launches):
