@@ -165,12 +165,17 @@ def run_config(args, world, rank, dev, group, weights, fif, steps, warmup, nwin=
     from diga_amd.engine import Engine
     from diga_amd.pipeline import StreamWindows
     H, W = args.height, args.width
+    kw = dict(bn_lambda=CFG["bn_lambda"], autotune=not args.no_autotune, force_exchange=args.rehearse_exchange)
     if nwin > 1:
-        sw = StreamWindows(weights, fif, nwin, H, W, bn_lambda=CFG["bn_lambda"], autotune=not args.no_autotune)
+        groups = None
+        if group is not None:         # one process group (communicator) per window: see StreamWindows
+            import torch.distributed as dist
+            groups = [group] + [dist.new_group(backend=dist.get_backend(group)) for _ in range(nwin - 1)]
+        sw = StreamWindows(weights, fif, nwin, H, W, groups=groups, **kw)
         eng = sw.engines[0]
     else:
         sw = None
-        eng = Engine(weights, fif, H, W, bn_lambda=CFG["bn_lambda"], group=group, stream=fif > 1, autotune=not args.no_autotune)
+        eng = Engine(weights, fif, H, W, group=group, stream=fif > 1, **kw)
     nf = 4 if fif == 1 else 2
     frames = []
     for i in range(nf * nwin):
@@ -187,7 +192,7 @@ def run_config(args, world, rank, dev, group, weights, fif, steps, warmup, nwin=
         eng.forward_and_adapt(x, y, CFG)
         eng.tail(y)
 
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = (world == 1) and not args.no_graph and not args.rehearse_exchange
     step_eager(0)
     step_eager(1)
     torch.cuda.synchronize()
@@ -253,8 +258,19 @@ def main():
     ap.add_argument("--no-calibration", action="store_true", help="skip the library-GEMM / device-copy peak check")
     ap.add_argument("--no-latency-mode", action="store_true", help="skip the extra one-frame-per-step measurement")
     ap.add_argument("--no-miou", action="store_true", help="skip the mIoU-vs-reference leg (8 frames through the measured configuration)")
+    ap.add_argument("--rehearse-exchange", action="store_true",
+                    help="N=1 only: run the N>1 code path (eager launches, one window, per-layer reduce_slab + RCCL all-reduce + "
+                         "finalize_sums, prototype exchange) through a single-rank nccl group: what the sharded step costs before any "
+                         "cross-GPU latency (not a bench line)")
     ap.add_argument("--dump", default=None, help="write the per-conv timing table to this JSON file")
     args = ap.parse_args()
+
+    # The contract is ONE JSON line on stdout.  Native libraries print banners there (RCCL's version block, gloo's
+    # "Rank 0 is connected to ..."), so file descriptor 1 is pointed at stderr for the run and the JSON line is written to
+    # the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -273,6 +289,11 @@ def main():
         else:
             dist.init_process_group(backend)
         group = dist.group.WORLD
+    elif args.rehearse_exchange:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29700 + os.getpid() % 200}", rank=0, world_size=1, device_id=dev)
+        group = dist.group.WORLD
+        args.no_miou, args.no_latency_mode = True, True
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from diga_amd import synth
@@ -280,7 +301,7 @@ def main():
     H, W = args.height, args.width
     weights = NetWeights(synth.synth_params(0), dev)
     fif = max(1, args.frames_in_flight)
-    nwin = max(1, args.windows) if world == 1 else 1
+    nwin = max(1, args.windows)
     fps, ms_per_step, eng, frames, use_graph = run_config(args, world, rank, dev, group, weights, fif, args.steps, args.warmup, nwin)
 
     res = {
@@ -292,9 +313,10 @@ def main():
                                 "updates" + (f"; {nwin} window(s) of {fif} consecutive frames in flight per step (per-sample DAM statistics, "
                                              "SAM in stream order; bit-identical to one-frame steps)" if fif * nwin > 1 else "; one frame per step") if world == 1 else
                                 f"BASELINE configs[2]: global batch {world} = 1 frame per GPU, BN sum/sumsq + prototype sums all-reduced (RCCL)"
-                                + (f"; {fif} consecutive global batches in flight per step (one exchange per BN layer for all of them)" if fif > 1 else "")),
+                                + (f"; {nwin} window(s) of {fif} consecutive global batches in flight per step (one exchange per BN layer for all "
+                                   "batches of a window; each window on its own HIP stream and RCCL communicator)" if fif * nwin > 1 else "")),
                    "resolution": f"{W}x{H}", "feature_grid": f"{eng.wd}x{eng.h}", "weights": "seeded synthetic init (diga_amd/synth.py)",
-                   "launch": "hipGraph replay" if use_graph else "eager", "backend": backend if world > 1 else None, "conv_tiles": "autotuned per shape" if eng.autotune else "fixed rule",
+                   "launch": "hipGraph replay" if use_graph else "eager", "backend": backend if world > 1 else ("nccl, single-rank rehearsal of the exchange path" if args.rehearse_exchange else None), "conv_tiles": "autotuned per shape" if eng.autotune else "fixed rule",
                    "includes": "net + SAM + fusion + upsample/argmax/confusion tail",
                    "frames_per_step": fif * nwin, "windows": nwin, "conv_gflop_per_frame": round(eng.conv_flops / fif / 1e9, 3)},
     }
@@ -332,8 +354,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(res), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+    if world > 1 or args.rehearse_exchange:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -15,9 +15,17 @@ from .engine import Engine, NetWeights
 
 
 class StreamWindows:
-    def __init__(self, weights: NetWeights, k: int, nwin: int, H: int, W: int, **engine_kw):
+    def __init__(self, weights: NetWeights, k: int, nwin: int, H: int, W: int, groups=None, **engine_kw):
+        """groups: None, or one torch.distributed process group PER WINDOW (the sharded form: every window holds this
+        rank's frame of k consecutive global batches).  Each window needs its own group -- its own RCCL communicator and
+        communicator stream -- because a communicator runs its collectives in issue order: with one shared group window
+        w+1's first BN exchange would queue behind all 104 of window w's and the trunks could not overlap.  Every rank
+        creates the groups and issues each group's collectives in the same order, so the usual ordering rule holds per
+        communicator."""
         self.k, self.nwin = k, nwin
-        self.engines = [Engine(weights, k, H, W, stream=k > 1 or nwin > 1, **engine_kw) for _ in range(nwin)]
+        assert groups is None or len(groups) == nwin
+        self.engines = [Engine(weights, k, H, W, stream=k > 1 or nwin > 1, group=None if groups is None else groups[i], **engine_kw)
+                        for i in range(nwin)]
         e0 = self.engines[0]
         for e in self.engines[1:]:               # one cross-frame state (ttda:1702-1705) and one metric for all windows
             e.run_proto, e.run_flag, e.state_flag, e.hist = e0.run_proto, e0.run_flag, e0.state_flag, e0.hist

@@ -18,7 +18,7 @@ def _worker(rank, world, port, q, k):
     os.makedirs("gpurun_out", exist_ok=True)
     log = open(f"gpurun_out/dist_rank{rank}.log", "w")
     try:
-        (_worker_stream if k > 1 else _worker_body)(rank, world, port, q, log, k)
+        (_worker_windows if k < 0 else _worker_stream if k > 1 else _worker_body)(rank, world, port, q, log, k)
     except Exception:
         traceback.print_exc(file=log)
         log.flush()
@@ -75,6 +75,36 @@ def _worker_stream(rank, world, port, q, log, k):
         pass
 
 
+def _worker_windows(rank, world, port, q, log, k):
+    """Two windows (each on its own HIP stream and its own process group) of k global batches in flight."""
+    import torch.distributed as dist
+    from diga_amd import synth
+    from diga_amd.engine import NetWeights
+    from diga_amd.pipeline import StreamWindows
+    k = -k
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    groups = [dist.group.WORLD, dist.new_group(backend="gloo")]
+    w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
+    sw = StreamWindows(w, k, 2, H, W, groups=groups)
+    wins = []
+    for i in range(2):
+        xy = [synth.synth_frame(i * k + t, world, H, W) for t in range(k)]
+        wins.append((torch.from_numpy(np.concatenate([a[rank:rank + 1] for a, _ in xy])).cuda(),
+                     torch.from_numpy(np.concatenate([b[rank:rank + 1] for _, b in xy])).cuda()))
+    probs = sw.step(wins, CFG)
+    torch.cuda.synchronize()
+    print("step done", file=log, flush=True)
+    out = dict(probs=np.concatenate([p.cpu().numpy() for p in probs]), logits=np.concatenate([e.logits.cpu().numpy() for e in sw.engines]),
+               run=sw.engines[0].run_proto.cpu().numpy(), rflag=sw.engines[0].run_flag.cpu().numpy(), hist=sw.engines[0].hist.cpu().numpy())
+    dist.barrier()
+    q.put((rank, out))
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
 def _run_ranks(k):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -100,6 +130,28 @@ def test_two_ranks_stream_of_global_batches():
     w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
     eng = Engine(w, 2, H, W)
     for t in range(K):
+        x, y = synth.synth_frame(t, 2, H, W)
+        probs = eng.forward_and_adapt(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), CFG)
+        torch.cuda.synchronize()
+        for r in range(2):
+            assert np.array_equal(res[r]["logits"][t], eng.logits.cpu().numpy()[r]), (t, r)
+            a, b = res[r]["probs"][t], probs.cpu().numpy()[r]
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.nanmax(np.abs(a - b)) < 1e-4, (t, r)
+    ref_run = eng.run_proto.cpu().numpy()
+    assert np.array_equal(res[0]["run"], res[1]["run"]) and np.array_equal(res[0]["rflag"], eng.run_flag.cpu().numpy())
+    assert np.abs(res[0]["run"] - ref_run).max() <= 1e-5 * np.abs(ref_run).max()
+
+
+def test_two_ranks_two_windows_of_global_batches():
+    """2 windows x 2 global batches of 2 on 2 ranks, each window with its own process group and HIP stream == the
+    single-process batch-2 engine run batch after batch (trunk bit-identical, SAM state up to fp32 rounding)."""
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    K = 2
+    res = _run_ranks(-K)
+    w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
+    eng = Engine(w, 2, H, W)
+    for t in range(2 * K):
         x, y = synth.synth_frame(t, 2, H, W)
         probs = eng.forward_and_adapt(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), CFG)
         torch.cuda.synchronize()
@@ -176,6 +228,22 @@ def _rccl_worker(port, q):
                 a.forward_and_adapt(x, y, CFG)
             torch.cuda.synchronize()
             print(f"eager step with 104 + 2 RCCL all-reduces: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", file=log, flush=True)
+        # two windows, each with its own communicator and HIP stream, against two windows without a group
+        from diga_amd.pipeline import StreamWindows
+        groups = [dist.group.WORLD, dist.new_group(backend="nccl")]
+        sa = StreamWindows(w, 2, 2, H, W, groups=groups, force_exchange=True)
+        sb = StreamWindows(w, 2, 2, H, W)
+        for rep in range(2):
+            wins = []
+            for i in range(2):
+                xy = [synth.synth_frame(4 * rep + 2 * i + t, 1, H, W) for t in range(2)]
+                wins.append((torch.from_numpy(np.concatenate([a_ for a_, _ in xy])).cuda(), torch.from_numpy(np.concatenate([b_ for _, b_ in xy])).cuda()))
+            pa, pb = sa.step(wins, CFG), sb.step(wins, CFG)
+            torch.cuda.synchronize()
+            same = all(torch.equal(torch.nan_to_num(u, nan=-1.0), torch.nan_to_num(v, nan=-1.0)) for u, v in zip(pa, pb)) and \
+                torch.equal(sa.engines[0].run_proto, sb.engines[0].run_proto) and torch.equal(sa.engines[0].hist, sb.engines[0].hist)
+            print("two windows, step", rep, "bit-identical" if same else "DIFFERENT", file=log, flush=True)
+            ok = ok and same
         dist.barrier()
         dist.destroy_process_group()
         q.put(ok)
