@@ -161,8 +161,9 @@ __global__ __launch_bounds__(64) void proto_index_kernel(const int32_t* __restri
 
 __global__ __launch_bounds__(256) void proto_pool_kernel(const unsigned short* __restrict__ feat, const int32_t* __restrict__ idx,
                                                          const int32_t* __restrict__ counts, int64_t P, int C, int CH, int CS,
-                                                         int JC, float* __restrict__ partial) {
-  const int j = blockIdx.x, c = blockIdx.y, s = blockIdx.z;
+                                                         int JC, float* __restrict__ partial, int nsets) {
+  const int j = blockIdx.x, c = blockIdx.y, s = blockIdx.z;      // s = frame * nsets + set: every frame has its own features
+  feat += (size_t)(s / nsets) * P * CH;
   const int n = counts[s * C + c];
   const int beg = j * CS;
   if (beg >= n) return;
@@ -465,7 +466,7 @@ struct PoolPlan {
   int CS, JC;
   int64_t idx_bytes, partial_bytes;
 };
-PoolPlan pool_plan(int nsets, int64_t P, int C, int CH) {
+PoolPlan pool_plan(int nsets, int64_t P, int C, int CH) {      // nsets = label sets in the call (frames x sets per frame)
   PoolPlan pp;
   // chunk = list positions one block sums: ~P/256 so that the dominant classes alone spread over the whole chip
   // (a chunk is a latency-bound chain of row reads; the partial buffer costs nsets*C*JC*CH floats)
@@ -478,28 +479,39 @@ PoolPlan pool_plan(int nsets, int64_t P, int C, int CH) {
 }
 }  // namespace
 
-extern "C" int64_t diga_proto_pool_work_bytes(int nsets, int64_t P, int C, int CH) {
-  if (nsets < 1 || nsets > 2 || P <= 0 || C <= 0 || CH <= 0) return DIGA_EINVAL;
-  const PoolPlan pp = pool_plan(nsets, P, C, CH);
+extern "C" int64_t diga_proto_pool_frames_work_bytes(int nframes, int nsets, int64_t P, int C, int CH) {
+  if (nframes < 1 || nframes > 4096 || nsets < 1 || nsets > 2 || P <= 0 || C <= 0 || CH <= 0) return DIGA_EINVAL;
+  const PoolPlan pp = pool_plan(nframes * nsets, P, C, CH);
   return pp.idx_bytes + pp.partial_bytes;
+}
+
+extern "C" int64_t diga_proto_pool_work_bytes(int nsets, int64_t P, int C, int CH) {
+  return diga_proto_pool_frames_work_bytes(1, nsets, P, C, CH);
+}
+
+extern "C" int diga_proto_pool_frames(const void* feat, const int32_t* labels, int nframes, int nsets, int64_t P, int C, int CH,
+                                      void* work, float* sums, int32_t* counts, void* stream) {
+  DIGA_CHECK_ARG(feat && labels && work && sums && counts, "diga_proto_pool: NULL pointer");
+  DIGA_CHECK_ARG(nframes >= 1 && nframes <= 4096 && nsets >= 1 && nsets <= 2 && P > 0 && P < (1ll << 31) && C > 0 &&
+                     C <= DIGA_NUM_CLASSES_MAX && CH > 0 && CH % 8 == 0 && (int64_t)nframes * nsets * C <= 65535,
+                 "diga_proto_pool: bad sizes");
+  const int ns = nframes * nsets;
+  const PoolPlan pp = pool_plan(ns, P, C, CH);
+  int32_t* idx = (int32_t*)work;
+  float* partial = (float*)((char*)work + pp.idx_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(proto_index_kernel, dim3(C, ns), dim3(64), 0, st, labels, P, C, idx, counts);
+  hipLaunchKernelGGL(proto_pool_kernel, dim3(pp.JC, C, ns), dim3(256), 0, st, (const unsigned short*)feat, idx, counts, P, C, CH,
+                     pp.CS, pp.JC, partial, nsets);
+  hipLaunchKernelGGL(proto_reduce_kernel, dim3(cdiv(CH, 256), ns * C), dim3(256), 0, st, partial, counts, C, CH, pp.CS, pp.JC,
+                     sums);
+  DIGA_CHECK_LAUNCH("diga_proto_pool");
+  return DIGA_OK;
 }
 
 extern "C" int diga_proto_pool(const void* feat, const int32_t* labels, int nsets, int64_t P, int C, int CH, void* work,
                                float* sums, int32_t* counts, void* stream) {
-  DIGA_CHECK_ARG(feat && labels && work && sums && counts, "diga_proto_pool: NULL pointer");
-  DIGA_CHECK_ARG(nsets >= 1 && nsets <= 2 && P > 0 && P < (1ll << 31) && C > 0 && C <= DIGA_NUM_CLASSES_MAX && CH > 0 && CH % 8 == 0,
-                 "diga_proto_pool: bad sizes");
-  const PoolPlan pp = pool_plan(nsets, P, C, CH);
-  int32_t* idx = (int32_t*)work;
-  float* partial = (float*)((char*)work + pp.idx_bytes);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(proto_index_kernel, dim3(C, nsets), dim3(64), 0, st, labels, P, C, idx, counts);
-  hipLaunchKernelGGL(proto_pool_kernel, dim3(pp.JC, C, nsets), dim3(256), 0, st, (const unsigned short*)feat, idx, counts, P, C, CH,
-                     pp.CS, pp.JC, partial);
-  hipLaunchKernelGGL(proto_reduce_kernel, dim3(cdiv(CH, 256), nsets * C), dim3(256), 0, st, partial, counts, C, CH, pp.CS, pp.JC,
-                     sums);
-  DIGA_CHECK_LAUNCH("diga_proto_pool");
-  return DIGA_OK;
+  return diga_proto_pool_frames(feat, labels, 1, nsets, P, C, CH, work, sums, counts, stream);
 }
 
 extern "C" int diga_proto_update(const float* sums, const int32_t* counts, int C, int CH, float* inst_proto, float* inst_flag,

@@ -217,7 +217,7 @@ class Engine:
         # labels: batch mode [2][P] = [pseudo | ground truth] over the batch; stream mode [B][2][hw] (per frame)
         self.labels = buf(2 * self.P, i32)
         self.Ps = self.hw if self.stream else self.P             # pixels one SAM pass pools over
-        self.pool_work = torch.empty(int(_lib.load().diga_proto_pool_work_bytes(2, self.Ps, self.C, FEAT_CH)),
+        self.pool_work = torch.empty(int(_lib.load().diga_proto_pool_frames_work_bytes(self.na, 2, self.Ps, self.C, FEAT_CH)),
                                      dtype=torch.uint8, device=dev)
         self.pcf_work = torch.empty(int(_lib.load().diga_proto_classify_work_bytes(self.Ps, FEAT_CH)), dtype=torch.uint8, device=dev)
         self.pool_sums = torch.zeros(self.na * 2 * self.C * FEAT_CH, dtype=f32, device=dev)      # per frame in stream mode
@@ -476,11 +476,10 @@ class Engine:
         # frames are pooled first and (sharded) exchanged in one collective.
         nset = B if self.stream else 1
         SC = 2 * Cn * FEAT_CH
-        for s in range(nset):
-            feat = self.feat[s * hw * FEAT_CH:] if self.stream else self.feat
-            labels = self.labels[s * 2 * hw:] if self.stream else self.labels
-            call("diga_proto_pool", _p(feat), _p(labels), 2, Ps, Cn, FEAT_CH, _p(self.pool_work), _p(self.pool_sums[s * SC:]),
-                 _p(self.pool_counts[s * 2 * Cn:]), _stream())
+        # (stream mode: labels are [frame][pseudo | gt][hw], features [frame][hw][CH], sums [frame][2][C][CH] -- one set of
+        # launches pools every frame, each bit-identical to its own call)
+        call("diga_proto_pool_frames", _p(self.feat), _p(self.labels), nset, 2, Ps, Cn, FEAT_CH, _p(self.pool_work), _p(self.pool_sums),
+             _p(self.pool_counts), _stream())
         if self.exchange:
             self._all_reduce(self.pool_sums)
             self._all_reduce(self.pool_counts)

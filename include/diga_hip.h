@@ -180,6 +180,13 @@ int diga_nearest_down_labels(const void* y, int y_is_i64, int32_t* out, int B, i
 int64_t diga_proto_pool_work_bytes(int nsets, int64_t P, int C, int CH);
 int diga_proto_pool(const void* feat, const int32_t* labels, int nsets, int64_t P, int C, int CH,
                     void* work, float* sums, int32_t* counts, void* stream);
+/* The same for nframes independent frames in one set of launches (a stream of batch-1 frames in flight: pooling does
+ * not depend on the running prototypes, so all frames are pooled before the per-frame EMA / classifier chain).
+ * feat: bf16 [nframes][P][CH]; labels: int32 [nframes][nsets][P]; sums: fp32 [nframes][nsets][C][CH]; counts: int32
+ * [nframes][nsets][C]; every frame's result is bit-identical to its own diga_proto_pool call. */
+int64_t diga_proto_pool_frames_work_bytes(int nframes, int nsets, int64_t P, int C, int CH);
+int diga_proto_pool_frames(const void* feat, const int32_t* labels, int nframes, int nsets, int64_t P, int C,
+                           int CH, void* work, float* sums, int32_t* counts, void* stream);
 
 /* Instance prototypes + running-prototype seed / EMA (ttda:1700-1705, 1736-1765).
  * sums/counts: as produced by diga_proto_pool with set 0 = pseudo-labels, set 1 = ground truth
