@@ -258,6 +258,67 @@ __global__ void proto_flags_kernel(const int32_t* __restrict__ counts, int C, fl
   if (c == 0) *state_flag = 1;
 }
 
+// The same chain for F consecutive batch-1 frames of a stream in ONE launch pair: thread (c, ch) walks the frames in
+// order with the running value in a register (flags and the seeded state evolve identically in every thread: they
+// depend on the counts only) and stores, per frame, the instance prototype and the running prototype AFTER that
+// frame's update -- what frame f's classifier reads.  Arithmetic per frame = proto_update_kernel's.
+__global__ void proto_update_frames_kernel(const float* __restrict__ sums, const int32_t* __restrict__ counts, int F, int C, int CH,
+                                           float* __restrict__ inst_protos, float* __restrict__ run_protos,
+                                           float* __restrict__ run_proto, const float* __restrict__ run_flag,
+                                           const int32_t* __restrict__ state_flag, float omr, float rho) {
+  const int c = blockIdx.y;
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= CH) return;
+  bool seeded = *state_flag != 0;
+  float run = run_proto[(size_t)c * CH + ch];
+  float rf = run_flag[c];
+  for (int f = 0; f < F; ++f) {
+    const int32_t* cnt = counts + (size_t)f * 2 * C;
+    const float* sm = sums + (size_t)f * 2 * C * CH;
+    const int n_pl = cnt[c], n_gt = cnt[C + c];
+    const float inst = n_pl > 0 ? sm[(size_t)c * CH + ch] / (float)n_pl : 0.f;
+    inst_protos[((size_t)f * C + c) * CH + ch] = inst;
+    if (!seeded) {
+      run = inst;
+      rf = n_pl > 0 ? 1.f : 0.f;
+    } else if (n_gt > 0 && rho != 0.f) {
+      const float gt = sm[((size_t)C + c) * CH + ch] / (float)n_gt;
+      if (rf == 0.f) {
+        run = gt;
+        rf = 1.f;
+      } else {
+        run = omr * run + rho * gt;
+      }
+    }
+    seeded = true;
+    run_protos[((size_t)f * C + c) * CH + ch] = run;
+  }
+  run_proto[(size_t)c * CH + ch] = run;
+}
+
+__global__ void proto_flags_frames_kernel(const int32_t* __restrict__ counts, int F, int C, float* __restrict__ inst_flags,
+                                          float* __restrict__ run_flags, float* __restrict__ run_flag,
+                                          int32_t* __restrict__ state_flag, float rho) {
+  const int c = threadIdx.x;
+  bool seeded = *state_flag != 0;
+  __syncthreads();
+  if (c < C) {
+    float rf = run_flag[c];
+    for (int f = 0; f < F; ++f) {
+      const int n_pl = counts[(size_t)f * 2 * C + c], n_gt = counts[(size_t)f * 2 * C + C + c];
+      inst_flags[f * C + c] = n_pl > 0 ? 1.f : 0.f;
+      if (!seeded)
+        rf = n_pl > 0 ? 1.f : 0.f;
+      else if (n_gt > 0 && rho != 0.f)
+        rf = 1.f;
+      seeded = true;
+      run_flags[f * C + c] = rf;
+    }
+    run_flag[c] = rf;
+  }
+  if (c == 0) *state_flag = 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // prototype-distance classifier x2 + blend + softmax fusion (ttda:1707-1709, 1712-1734, 1644)
 // Squared distances are accumulated directly, sum (p - f)^2 in fp32 -- no ||f||^2 - 2 f.p + ||p||^2 expansion
@@ -279,6 +340,9 @@ __global__ void proto_transpose_kernel(const float* __restrict__ inst_proto, con
                                        float* __restrict__ protoT, int C, int CH) {
   const int e = blockIdx.x * 256 + threadIdx.x;          // one thread per (ch, padded slot)
   if (e >= CH * 64) return;
+  inst_proto += (size_t)blockIdx.y * C * CH;             // blockIdx.y = prototype set (one per frame of a stream in flight)
+  run_proto += (size_t)blockIdx.y * C * CH;
+  protoT += (size_t)blockIdx.y * CH * 64;
   const int ch = e >> 6, g = (e >> 3) & 7, j = e & 7, k = g * 5 + j;
   float v = 0.f;
   if (j < 5) {
@@ -291,11 +355,15 @@ __global__ void proto_transpose_kernel(const float* __restrict__ inst_proto, con
 }
 
 __global__ __launch_bounds__(128) void proto_dist_kernel(const unsigned short* __restrict__ feat, const float* __restrict__ protoT,
-                                                         float* __restrict__ work, int64_t P, int CH, int ch_per_split) {
+                                                         float* __restrict__ work, int64_t P, int CH, int ch_per_split, int hw,
+                                                         int bps, int64_t proto_set_stride) {
   __shared__ __attribute__((aligned(16))) float sf[64][PCF_PITCH];   // [ch][px]
   __shared__ __attribute__((aligned(16))) float spr[64][8][8];       // [ch][slot group][5 used of 8]
   const int tid = threadIdx.x, pg = tid & 15, sg = tid >> 4;
-  const int64_t p0 = (int64_t)blockIdx.x * PCF_PIX;
+  // blocks never straddle samples (bps blocks per sample), so that every sample can have its own prototypes
+  const int smp = blockIdx.x / bps, pix0 = (blockIdx.x - smp * bps) * PCF_PIX;
+  const int64_t p0 = (int64_t)smp * hw + pix0;
+  protoT += (size_t)smp * proto_set_stride;
   const int chb = blockIdx.y * ch_per_split;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 acc[2][5];                       // [pixel pair][prototype]: packed fp32 (v_pk_add_f32 / v_pk_fma_f32)
@@ -311,7 +379,7 @@ __global__ __launch_bounds__(128) void proto_dist_kernel(const unsigned short* _
 #pragma unroll
     for (int j = 0; j < 4; ++j) {            // feature tile: 64 px x 8 octets, 4 per thread; 8 lanes read one 128-B row
       const int id = tid + 128 * j, r = id >> 3, o = id & 7;
-      fr[j] = p0 + r < P ? *reinterpret_cast<const u32x4*>(feat + (size_t)(p0 + r) * CH + ch0 + o * 8) : u32x4{0u, 0u, 0u, 0u};
+      fr[j] = pix0 + r < hw ? *reinterpret_cast<const u32x4*>(feat + (size_t)(p0 + r) * CH + ch0 + o * 8) : u32x4{0u, 0u, 0u, 0u};
     }
     const f32x4* src = reinterpret_cast<const f32x4*>(protoT + (size_t)ch0 * 64);   // prototype image: straight 16 KB copy
 #pragma unroll
@@ -355,7 +423,7 @@ __global__ __launch_bounds__(128) void proto_dist_kernel(const unsigned short* _
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t p = p0 + pg * 4 + i;
-    if (p < P) {
+    if (pix0 + pg * 4 + i < hw) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) w[p * PCF_SLOTS + sg * 5 + k] = acc[i >> 1][k][i & 1];
     }
@@ -371,7 +439,7 @@ constexpr int PFU_PX = 6;
 __global__ __launch_bounds__(256) void proto_fuse_kernel(const float* __restrict__ work, const float* __restrict__ logits,
                                                          const float* __restrict__ inst_flag, const float* __restrict__ run_flag,
                                                          float* __restrict__ out, int64_t P, int C, int hw, int nsplit, float tau,
-                                                         float pl, float pl1, float fl, float fl1) {
+                                                         float pl, float pl1, float fl, float fl1, int flag_set_stride) {
   __shared__ float sw[PFU_PX][PCF_SLOTS];
   __shared__ float sl[PFU_PX][DIGA_NUM_CLASSES_MAX];
   const int tid = threadIdx.x;
@@ -383,7 +451,8 @@ __global__ __launch_bounds__(256) void proto_fuse_kernel(const float* __restrict
     if (p < P && k < 2 * C) {
       float d = 0.f;
       for (int s = 0; s < nsplit; ++s) d += work[((size_t)s * P + p) * PCF_SLOTS + k];
-      w = expf(-sqrtf(d) / tau) * (k < C ? inst_flag[k] : run_flag[k - C]);
+      const int64_t fo = (p / hw) * flag_set_stride;         // per-sample flags when every sample has its own prototypes
+      w = expf(-sqrtf(d) / tau) * (k < C ? inst_flag[fo + k] : run_flag[fo + k - C]);
     }
     sw[px][k] = w;
   }
@@ -527,14 +596,32 @@ extern "C" int diga_proto_update(const float* sums, const int32_t* counts, int C
   return DIGA_OK;
 }
 
-extern "C" int64_t diga_proto_classify_work_bytes(int64_t P, int CH) {
-  if (P <= 0 || CH <= 0) return DIGA_EINVAL;
-  return (int64_t)CH * 64 * 4 + (int64_t)PCF_SPLIT * P * PCF_SLOTS * 4;     // protoT + partial squared distances
+extern "C" int diga_proto_update_frames(const float* sums, const int32_t* counts, int nframes, int C, int CH, float* inst_protos,
+                                        float* inst_flags, float* run_protos, float* run_flags, float* run_proto, float* run_flag,
+                                        int32_t* state_flag, float one_minus_rho, float rho, void* stream) {
+  DIGA_CHECK_ARG(sums && counts && inst_protos && inst_flags && run_protos && run_flags && run_proto && run_flag && state_flag,
+                 "diga_proto_update_frames: NULL pointer");
+  DIGA_CHECK_ARG(nframes > 0 && C > 0 && C <= DIGA_NUM_CLASSES_MAX && CH > 0, "diga_proto_update_frames: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(proto_update_frames_kernel, dim3(cdiv(CH, 256), C), dim3(256), 0, st, sums, counts, nframes, C, CH, inst_protos,
+                     run_protos, run_proto, run_flag, state_flag, one_minus_rho, rho);
+  hipLaunchKernelGGL(proto_flags_frames_kernel, dim3(1), dim3(64), 0, st, counts, nframes, C, inst_flags, run_flags, run_flag,
+                     state_flag, rho);
+  DIGA_CHECK_LAUNCH("diga_proto_update_frames");
+  return DIGA_OK;
 }
 
-extern "C" int diga_proto_classify_fuse(const void* feat, const float* logits, const float* inst_proto, const float* inst_flag,
-                                        const float* run_proto, const float* run_flag, float* out, void* work, int B, int C, int hw,
-                                        int CH, float tau, float pl, float pl1, float fl, float fl1, void* stream) {
+extern "C" int64_t diga_proto_classify_frames_work_bytes(int nsets, int64_t P, int CH) {
+  if (nsets <= 0 || P <= 0 || CH <= 0) return DIGA_EINVAL;
+  return (int64_t)nsets * CH * 64 * 4 + (int64_t)PCF_SPLIT * P * PCF_SLOTS * 4;     // protoT per set + partial squared distances
+}
+
+extern "C" int64_t diga_proto_classify_work_bytes(int64_t P, int CH) { return diga_proto_classify_frames_work_bytes(1, P, CH); }
+
+namespace {
+int classify_fuse(const void* feat, const float* logits, const float* inst_proto, const float* inst_flag, const float* run_proto,
+                  const float* run_flag, float* out, void* work, int B, int C, int hw, int CH, float tau, float pl, float pl1, float fl,
+                  float fl1, int per_sample, void* stream) {
   DIGA_CHECK_ARG(feat && logits && inst_proto && inst_flag && run_proto && run_flag && out && work, "diga_proto_classify_fuse: NULL pointer");
   DIGA_CHECK_ARG(B > 0 && hw > 0 && C > 0 && 2 * C <= PCF_SLOTS && CH > 0 && CH % 64 == 0,
                  "diga_proto_classify_fuse: bad sizes (C <= 20, CH %% 64 == 0)");
@@ -543,12 +630,30 @@ extern "C" int diga_proto_classify_fuse(const void* feat, const float* logits, c
   while ((CH / 64) % nsplit) --nsplit;
   hipStream_t st = (hipStream_t)stream;
   float* protoT = (float*)work;
-  float* partial = protoT + (size_t)CH * 64;
-  hipLaunchKernelGGL(proto_transpose_kernel, dim3(cdiv(CH * 64, 256)), dim3(256), 0, st, inst_proto, run_proto, protoT, C, CH);
-  hipLaunchKernelGGL(proto_dist_kernel, dim3(cdiv(P, PCF_PIX), nsplit), dim3(128), 0, st, (const unsigned short*)feat, protoT,
-                     partial, P, CH, CH / nsplit);
+  float* partial;
+  const int nsets = per_sample ? B : 1;
+  const int bps = cdiv(hw, PCF_PIX);
+  DIGA_CHECK_ARG((int64_t)B * bps < (1ll << 31), "diga_proto_classify_fuse: too many pixels");
+  partial = protoT + (size_t)nsets * CH * 64;
+  hipLaunchKernelGGL(proto_transpose_kernel, dim3(cdiv(CH * 64, 256), nsets), dim3(256), 0, st, inst_proto, run_proto, protoT, C, CH);
+  hipLaunchKernelGGL(proto_dist_kernel, dim3(B * bps, nsplit), dim3(128), 0, st, (const unsigned short*)feat, protoT, partial, P, CH,
+                     CH / nsplit, hw, bps, per_sample ? (int64_t)CH * 64 : 0);
   hipLaunchKernelGGL(proto_fuse_kernel, dim3(cdiv(P, PFU_PX)), dim3(256), 0, st, (const float*)partial, logits, inst_flag, run_flag, out,
-                     P, C, hw, nsplit, tau, pl, pl1, fl, fl1);
+                     P, C, hw, nsplit, tau, pl, pl1, fl, fl1, per_sample ? C : 0);
   DIGA_CHECK_LAUNCH("diga_proto_classify_fuse");
   return DIGA_OK;
+}
+}  // namespace
+
+extern "C" int diga_proto_classify_fuse(const void* feat, const float* logits, const float* inst_proto, const float* inst_flag,
+                                        const float* run_proto, const float* run_flag, float* out, void* work, int B, int C, int hw,
+                                        int CH, float tau, float pl, float pl1, float fl, float fl1, void* stream) {
+  return classify_fuse(feat, logits, inst_proto, inst_flag, run_proto, run_flag, out, work, B, C, hw, CH, tau, pl, pl1, fl, fl1, 0, stream);
+}
+
+extern "C" int diga_proto_classify_fuse_frames(const void* feat, const float* logits, const float* inst_protos, const float* inst_flags,
+                                               const float* run_protos, const float* run_flags, float* out, void* work, int nframes,
+                                               int C, int hw, int CH, float tau, float pl, float pl1, float fl, float fl1, void* stream) {
+  return classify_fuse(feat, logits, inst_protos, inst_flags, run_protos, run_flags, out, work, nframes, C, hw, CH, tau, pl, pl1, fl, fl1,
+                       1, stream);
 }

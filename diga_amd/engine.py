@@ -219,11 +219,15 @@ class Engine:
         self.Ps = self.hw if self.stream else self.P             # pixels one SAM pass pools over
         self.pool_work = torch.empty(int(_lib.load().diga_proto_pool_frames_work_bytes(self.na, 2, self.Ps, self.C, FEAT_CH)),
                                      dtype=torch.uint8, device=dev)
-        self.pcf_work = torch.empty(int(_lib.load().diga_proto_classify_work_bytes(self.Ps, FEAT_CH)), dtype=torch.uint8, device=dev)
+        self.pcf_work = torch.empty(int(_lib.load().diga_proto_classify_frames_work_bytes(self.na, self.P, FEAT_CH)), dtype=torch.uint8,
+                                    device=dev)
         self.pool_sums = torch.zeros(self.na * 2 * self.C * FEAT_CH, dtype=f32, device=dev)      # per frame in stream mode
         self.pool_counts = torch.zeros(self.na * 2 * self.C, dtype=i32, device=dev)
-        self.inst_proto = torch.zeros(self.C, FEAT_CH, dtype=f32, device=dev)
-        self.inst_flag = torch.zeros(self.C, dtype=f32, device=dev)
+        # stream mode keeps every frame's instance prototypes and the running prototypes after that frame's update
+        self.inst_proto = torch.zeros(self.na, self.C, FEAT_CH, dtype=f32, device=dev)
+        self.inst_flag = torch.zeros(self.na, self.C, dtype=f32, device=dev)
+        self.run_protos = torch.zeros(self.na, self.C, FEAT_CH, dtype=f32, device=dev) if self.stream else None
+        self.run_flags = torch.zeros(self.na, self.C, dtype=f32, device=dev) if self.stream else None
         self.run_proto = torch.zeros(self.C, FEAT_CH, dtype=f32, device=dev)
         self.run_flag = torch.zeros(self.C, dtype=f32, device=dev)
         self.state_flag = torch.zeros(1, dtype=i32, device=dev)
@@ -475,7 +479,6 @@ class Engine:
         # prototypes of frame t feed frame t+1, ttda:1702-1705).  Pooling does not depend on the running state, so all
         # frames are pooled first and (sharded) exchanged in one collective.
         nset = B if self.stream else 1
-        SC = 2 * Cn * FEAT_CH
         # (stream mode: labels are [frame][pseudo | gt][hw], features [frame][hw][CH], sums [frame][2][C][CH] -- one set of
         # launches pools every frame, each bit-identical to its own call)
         call("diga_proto_pool_frames", _p(self.feat), _p(self.labels), nset, 2, Ps, Cn, FEAT_CH, _p(self.pool_work), _p(self.pool_sums),
@@ -483,16 +486,20 @@ class Engine:
         if self.exchange:
             self._all_reduce(self.pool_sums)
             self._all_reduce(self.pool_counts)
-        for s in range(nset):
-            feat = self.feat[s * hw * FEAT_CH:] if self.stream else self.feat
-            logits = self.logits[s:] if self.stream else self.logits
-            probs = self.probs[s:] if self.stream else self.probs
-            call("diga_proto_update", _p(self.pool_sums[s * SC:]), _p(self.pool_counts[s * 2 * Cn:]), Cn, FEAT_CH, _p(self.inst_proto),
-                 _p(self.inst_flag), _p(self.run_proto), _p(self.run_flag), _p(self.state_flag), float(np.float32(1 - rho)),
-                 float(np.float32(rho)), _stream())
-            call("diga_proto_classify_fuse", _p(feat), _p(logits), _p(self.inst_proto), _p(self.inst_flag),
-                 _p(self.run_proto), _p(self.run_flag), _p(probs), _p(self.pcf_work), 1 if self.stream else B, Cn, hw, FEAT_CH, 1.0,
-                 float(np.float32(pl)), float(np.float32(1 - pl)), float(np.float32(fl)), float(np.float32(1 - fl)), _stream())
+        coef = (float(np.float32(pl)), float(np.float32(1 - pl)), float(np.float32(fl)), float(np.float32(1 - fl)))
+        if self.stream:
+            # the frames' seed / EMA chain in stream order inside one launch pair (every frame's prototypes are kept), then
+            # ONE classifier pass in which frame f is measured against the prototypes as they stood after ITS update
+            call("diga_proto_update_frames", _p(self.pool_sums), _p(self.pool_counts), nset, Cn, FEAT_CH, _p(self.inst_proto),
+                 _p(self.inst_flag), _p(self.run_protos), _p(self.run_flags), _p(self.run_proto), _p(self.run_flag), _p(self.state_flag),
+                 float(np.float32(1 - rho)), float(np.float32(rho)), _stream())
+            call("diga_proto_classify_fuse_frames", _p(self.feat), _p(self.logits), _p(self.inst_proto), _p(self.inst_flag),
+                 _p(self.run_protos), _p(self.run_flags), _p(self.probs), _p(self.pcf_work), nset, Cn, hw, FEAT_CH, 1.0, *coef, _stream())
+            return self.probs
+        call("diga_proto_update", _p(self.pool_sums), _p(self.pool_counts), Cn, FEAT_CH, _p(self.inst_proto), _p(self.inst_flag),
+             _p(self.run_proto), _p(self.run_flag), _p(self.state_flag), float(np.float32(1 - rho)), float(np.float32(rho)), _stream())
+        call("diga_proto_classify_fuse", _p(self.feat), _p(self.logits), _p(self.inst_proto), _p(self.inst_flag), _p(self.run_proto),
+             _p(self.run_flag), _p(self.probs), _p(self.pcf_work), B, Cn, hw, FEAT_CH, 1.0, *coef, _stream())
         return self.probs
 
     def forward_and_adapt(self, x, y, cfg):

@@ -197,6 +197,16 @@ int diga_proto_update(const float* sums, const int32_t* counts, int C, int CH, f
                       float* inst_flag, float* run_proto, float* run_flag, int32_t* state_flag,
                       float one_minus_rho, float rho, void* stream);
 
+/* The same chain for nframes consecutive batch-1 frames of a stream in one launch pair (the frames' sums / counts come
+ * from diga_proto_pool_frames): frame f's instance prototypes and the running prototypes AFTER frame f's update --
+ * what frame f's classifier reads -- are stored per frame; run_proto / run_flag / state_flag carry the state in and out.
+ * sums fp32 [nframes][2][C][CH], counts int32 [nframes][2][C]; inst_protos, run_protos fp32 [nframes][C][CH];
+ * inst_flags, run_flags fp32 [nframes][C].  Every frame's values are bit-identical to nframes diga_proto_update calls. */
+int diga_proto_update_frames(const float* sums, const int32_t* counts, int nframes, int C, int CH,
+                             float* inst_protos, float* inst_flags, float* run_protos, float* run_flags,
+                             float* run_proto, float* run_flag, int32_t* state_flag, float one_minus_rho,
+                             float rho, void* stream);
+
 /* cal_pred_of_proto x2 + proto blend + softmax fusion (ttda:1707-1709,1712-1734,1644):
  *   out = fl*(pl*P_run + pl1*P_inst) + fl1*softmax(logits),  P_x[c] = exp(-||proto_x[c]-f||)*flag/sum
  * 0/0 -> NaN is reproduced.  feat bf16 [P][CH] (CH % 64 == 0); logits fp32 NCHW [B,C,hw]; out fp32 NCHW
@@ -206,6 +216,13 @@ int diga_proto_classify_fuse(const void* feat, const float* logits, const float*
                              const float* inst_flag, const float* run_proto, const float* run_flag,
                              float* out, void* work, int B, int C, int hw, int CH, float tau, float pl,
                              float pl1, float fl, float fl1, void* stream);
+/* The frames-in-flight form: sample f is classified against ITS prototypes and flags (the per-frame arrays of
+ * diga_proto_update_frames); work: diga_proto_classify_frames_work_bytes(nframes, P = nframes*hw, CH) bytes. */
+int64_t diga_proto_classify_frames_work_bytes(int nsets, int64_t P, int CH);
+int diga_proto_classify_fuse_frames(const void* feat, const float* logits, const float* inst_protos,
+                                    const float* inst_flags, const float* run_protos, const float* run_flags,
+                                    float* out, void* work, int nframes, int C, int hw, int CH, float tau,
+                                    float pl, float pl1, float fl, float fl1, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optional SAM extension (BASELINE.json north_star (2)).  NO counterpart in the reference: DIGA as
