@@ -25,7 +25,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void upsample_argmax_hist_kernel(const float* __restrict__ probs, const T* __restrict__ target,
                                                                    uint8_t* __restrict__ pred, unsigned long long* __restrict__ hist,
                                                                    float* __restrict__ probs_up, int B, int C, int h, int w, int H,
-                                                                   int W) {
+                                                                   int W, int hist_scale) {
   __shared__ unsigned int sh[DIGA_NUM_CLASSES_MAX * DIGA_NUM_CLASSES_MAX];
   for (int e = threadIdx.x; e < C * C; e += 256) sh[e] = 0;
   __syncthreads();
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void upsample_argmax_hist_kernel(const float* 
   }
   __syncthreads();
   for (int e = threadIdx.x; e < C * C; e += 256)
-    if (sh[e]) atomicAdd(&hist[e], (unsigned long long)sh[e] * (unsigned long long)B);   // ttda:165: hist * batch_size
+    if (sh[e]) atomicAdd(&hist[e], (unsigned long long)sh[e] * (unsigned long long)hist_scale);   // ttda:165: hist * batch_size
 }
 
 }  // namespace
@@ -70,18 +70,31 @@ void diga_set_error(const char* fmt, ...) {
 extern "C" const char* diga_last_error_string(void) { return g_err; }
 extern "C" int diga_version(void) { return 100; }
 
-extern "C" int diga_upsample_argmax_hist(const float* probs, const void* target, int target_is_i64, uint8_t* pred, int64_t* hist,
-                                         float* probs_up, int B, int C, int h, int w, int H, int W, void* stream) {
+namespace {
+int upsample_argmax_hist(const float* probs, const void* target, int target_is_i64, uint8_t* pred, int64_t* hist, float* probs_up, int B,
+                         int C, int h, int w, int H, int W, int hist_scale, void* stream) {
   DIGA_CHECK_ARG(probs && target && hist, "diga_upsample_argmax_hist: NULL pointer");
   DIGA_CHECK_ARG(B > 0 && C > 0 && C <= DIGA_NUM_CLASSES_MAX && h > 0 && w > 0 && H > 0 && W > 0, "diga_upsample_argmax_hist: bad sizes");
   const int64_t total = (int64_t)B * H * W;
-  const int grid = total / 256 < 2048 ? cdiv(total, 256) : 2048;
+  const int cap = 2048 * (B < 4 ? 1 : 4);
+  const int grid = total / 256 < cap ? cdiv(total, 256) : cap;
   if (target_is_i64)
     hipLaunchKernelGGL(upsample_argmax_hist_kernel<int64_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, probs,
-                       (const int64_t*)target, pred, (unsigned long long*)hist, probs_up, B, C, h, w, H, W);
+                       (const int64_t*)target, pred, (unsigned long long*)hist, probs_up, B, C, h, w, H, W, hist_scale);
   else
     hipLaunchKernelGGL(upsample_argmax_hist_kernel<int32_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, probs,
-                       (const int32_t*)target, pred, (unsigned long long*)hist, probs_up, B, C, h, w, H, W);
+                       (const int32_t*)target, pred, (unsigned long long*)hist, probs_up, B, C, h, w, H, W, hist_scale);
   DIGA_CHECK_LAUNCH("diga_upsample_argmax_hist");
   return DIGA_OK;
+}
+}  // namespace
+
+extern "C" int diga_upsample_argmax_hist(const float* probs, const void* target, int target_is_i64, uint8_t* pred, int64_t* hist,
+                                         float* probs_up, int B, int C, int h, int w, int H, int W, void* stream) {
+  return upsample_argmax_hist(probs, target, target_is_i64, pred, hist, probs_up, B, C, h, w, H, W, B, stream);
+}
+
+extern "C" int diga_upsample_argmax_hist_frames(const float* probs, const void* target, int target_is_i64, uint8_t* pred, int64_t* hist,
+                                                float* probs_up, int nframes, int C, int h, int w, int H, int W, void* stream) {
+  return upsample_argmax_hist(probs, target, target_is_i64, pred, hist, probs_up, nframes, C, h, w, H, W, 1, stream);
 }

@@ -517,10 +517,9 @@ class Engine:
                  _p(probs_up), self.B, self.C, self.h, self.wd, H, W, _stream())
             return self.pred
         # stream mode: the reference's metric sees batch-1 updates (its confusion matrix is scaled by the batch size,
-        # ttda:158-173), so every frame is its own call
-        for s in range(self.B):
-            call("diga_upsample_argmax_hist", _p(self.probs[s:]), _p(y[s:]), int(y.dtype == torch.int64), _p(self.pred[s:]),
-                 _p(self.hist), _p(probs_up[s:]) if probs_up is not None else None, 1, self.C, self.h, self.wd, H, W, _stream())
+        # ttda:158-173): one launch that counts every frame once
+        call("diga_upsample_argmax_hist_frames", _p(self.probs), _p(y), int(y.dtype == torch.int64), _p(self.pred), _p(self.hist),
+             _p(probs_up), self.B, self.C, self.h, self.wd, H, W, _stream())
         return self.pred
 
     def reset_state(self):
