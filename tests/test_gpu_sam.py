@@ -210,3 +210,81 @@ def test_tail_fixture(gold_tail):
     torch.cuda.synchronize()
     if safe.all():
         assert np.array_equal(hist.cpu().numpy().reshape(C_, C_), g["tail_hist2"].astype(np.int64))
+
+
+def test_frames_in_flight_entry_points_equal_per_frame_calls(gold_sam):
+    """diga_proto_pool_frames / diga_proto_update_frames / diga_proto_classify_fuse_frames / diga_upsample_argmax_hist_frames
+    on the 3-frame reference sequence (B = 1) in ONE launch set: bit-identical to the per-frame calls, and therefore equal
+    to the reference's multi_proto_label + fusion outputs of tests/golden/fn_sam.npz; a second window continues the state."""
+    g = gold_sam
+    F = 3
+    CH = g["mpl1_0_feat"].shape[1]
+    f32 = lambda v: float(np.float32(v))
+    feats = [T(g[f"mpl1_{t}_feat"]) for t in range(F)]
+    lgs = torch.cat([T(g[f"mpl1_{t}_logits"]) for t in range(F)]).to(DEV).contiguous()
+    ys = torch.cat([T(g[f"mpl1_{t}_y"]) for t in range(F)]).to(DEV).contiguous()
+    _, _, h, w = feats[0].shape
+    hw = h * w
+    feat = torch.cat([to_nhwc_bf16(f).reshape(-1) for f in feats]).contiguous()            # [F][hw][CH]
+    labels = torch.empty(F * 2 * hw, dtype=torch.int32, device=DEV)                        # [F][pseudo | gt][hw]
+    call("diga_head_finish_pseudo_label", None, 1, NC, None, P(lgs), None, P(labels), F, NC, hw, f32(0.9), 2 * hw, stream())
+    call("diga_nearest_down_labels", P(ys), 1, P(labels[hw:]), F, ys.shape[1], ys.shape[2], h, w, 2 * hw, stream())
+
+    def run_frames(state):
+        run, rflag, sflag, hist = state
+        work = torch.empty(call("diga_proto_pool_frames_work_bytes", F, 2, hw, NC, CH), dtype=torch.uint8, device=DEV)
+        sums = torch.empty(F * 2 * NC * CH, dtype=torch.float32, device=DEV)
+        counts = torch.empty(F * 2 * NC, dtype=torch.int32, device=DEV)
+        call("diga_proto_pool_frames", P(feat), P(labels), F, 2, hw, NC, CH, P(work), P(sums), P(counts), stream())
+        ip, rp = (torch.empty(F, NC, CH, dtype=torch.float32, device=DEV) for _ in range(2))
+        ifl, rfl = (torch.empty(F, NC, dtype=torch.float32, device=DEV) for _ in range(2))
+        call("diga_proto_update_frames", P(sums), P(counts), F, NC, CH, P(ip), P(ifl), P(rp), P(rfl), P(run), P(rflag), P(sflag),
+             f32(1 - 0.1), f32(0.1), stream())
+        out = torch.empty(F, NC, h, w, dtype=torch.float32, device=DEV)
+        cwork = torch.empty(call("diga_proto_classify_frames_work_bytes", F, F * hw, CH), dtype=torch.uint8, device=DEV)
+        call("diga_proto_classify_fuse_frames", P(feat), P(lgs), P(ip), P(ifl), P(rp), P(rfl), P(out), P(cwork), F, NC, hw, CH, 1.0,
+             f32(0.8), f32(1 - 0.8), f32(0.8), f32(1 - 0.8), stream())
+        pred = torch.empty(F, ys.shape[1], ys.shape[2], dtype=torch.uint8, device=DEV)
+        call("diga_upsample_argmax_hist_frames", P(out), P(ys), 1, P(pred), P(hist), None, F, NC, h, w, ys.shape[1], ys.shape[2], stream())
+        torch.cuda.synchronize()
+        return out, rp, rfl, pred
+
+    def run_per_frame(state):
+        run, rflag, sflag, hist = state
+        outs, rps, rfls, preds = [], [], [], []
+        inst = torch.empty(NC, CH, dtype=torch.float32, device=DEV)
+        iflag = torch.empty(NC, dtype=torch.float32, device=DEV)
+        for t in range(F):
+            ft, lab = feat[t * hw * CH:(t + 1) * hw * CH], labels[t * 2 * hw:(t + 1) * 2 * hw]
+            work = torch.empty(call("diga_proto_pool_work_bytes", 2, hw, NC, CH), dtype=torch.uint8, device=DEV)
+            sums = torch.empty(2 * NC * CH, dtype=torch.float32, device=DEV)
+            counts = torch.empty(2 * NC, dtype=torch.int32, device=DEV)
+            call("diga_proto_pool", P(ft), P(lab), 2, hw, NC, CH, P(work), P(sums), P(counts), stream())
+            call("diga_proto_update", P(sums), P(counts), NC, CH, P(inst), P(iflag), P(run), P(rflag), P(sflag), f32(1 - 0.1), f32(0.1),
+                 stream())
+            out = torch.empty(1, NC, h, w, dtype=torch.float32, device=DEV)
+            cwork = torch.empty(call("diga_proto_classify_work_bytes", hw, CH), dtype=torch.uint8, device=DEV)
+            call("diga_proto_classify_fuse", P(ft), P(lgs[t:]), P(inst), P(iflag), P(run), P(rflag), P(out), P(cwork), 1, NC, hw, CH, 1.0,
+                 f32(0.8), f32(1 - 0.8), f32(0.8), f32(1 - 0.8), stream())
+            pred = torch.empty(1, ys.shape[1], ys.shape[2], dtype=torch.uint8, device=DEV)
+            call("diga_upsample_argmax_hist", P(out), P(ys[t:]), 1, P(pred), P(hist), None, 1, NC, h, w, ys.shape[1], ys.shape[2], stream())
+            torch.cuda.synchronize()
+            outs.append(out), rps.append(run.clone()), rfls.append(rflag.clone()), preds.append(pred)
+        return torch.cat(outs), torch.stack(rps), torch.stack(rfls), torch.cat(preds)
+
+    def fresh():
+        return (torch.zeros(NC, CH, dtype=torch.float32, device=DEV), torch.zeros(NC, dtype=torch.float32, device=DEV),
+                torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(NC * NC, dtype=torch.int64, device=DEV))
+
+    sa, sb = fresh(), fresh()
+    for window in range(2):                       # the second window starts from the first one's state (EMA branch throughout)
+        a, b = run_frames(sa), run_per_frame(sb)
+        for u, v in zip(a, b):
+            assert torch.equal(torch.nan_to_num(u.float(), nan=-7.0), torch.nan_to_num(v.float(), nan=-7.0)), window
+        for u, v in zip(sa, sb):
+            assert torch.equal(u, v), window
+        if window == 0:
+            for t in range(F):
+                assert np.array_equal(a[2][t].cpu().numpy(), g[f"mpl1_{t}_rflag"]), t
+                assert rel_err(a[1][t].cpu(), g[f"mpl1_{t}_run"]) < 1e-5, t
+                nan_close(a[0][t:t + 1].cpu(), g[f"mpl1_{t}_fused"], 1e-4)
