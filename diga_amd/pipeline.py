@@ -29,6 +29,7 @@ class StreamWindows:
         e0 = self.engines[0]
         for e in self.engines[1:]:               # one cross-frame state (ttda:1702-1705) and one metric for all windows
             e.run_proto, e.run_flag, e.state_flag, e.hist = e0.run_proto, e0.run_flag, e0.state_flag, e0.hist
+            e.tile_cache = e0.tile_cache        # same shapes: the tile autotune runs once, in the first window
         self.streams = [torch.cuda.Stream() for _ in range(nwin)] if nwin > 1 else [None]
 
     def step(self, windows, cfg, tail: bool = True):
