@@ -57,6 +57,7 @@ SIGNATURES = {
     "diga_proto_classify_fuse_frames": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp]),
     "diga_proto_classify_work_bytes": (_i64, [_i64, _i]),
     "diga_proto_classify_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp]),
+    "diga_proto_classify_fuse_noalloc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp]),
     "diga_ccl_work_bytes": (_i64, [_i, _i, _i, _i]),
     "diga_ccl_label": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "diga_instance_pool_work_bytes": (_i64, [_i, _i64, _i, _i, _i]),

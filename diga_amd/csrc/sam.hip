@@ -1,5 +1,6 @@
 // Semantic Adaptation Module kernels (ttda_module.py:1662-1805) and the fusion line (ttda:1644).
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -651,9 +652,74 @@ extern "C" int diga_proto_classify_fuse(const void* feat, const float* logits, c
   return classify_fuse(feat, logits, inst_proto, inst_flag, run_proto, run_flag, out, work, B, C, hw, CH, tau, pl, pl1, fl, fl1, 0, stream);
 }
 
+extern "C" int diga_proto_classify_fuse_f32(const float* feat, const float* logits, const float* inst_proto, const float* inst_flag,
+                                            const float* run_proto, const float* run_flag, float* out, void* work, int B, int C, int hw,
+                                            int CH, float tau, float pl, float pl1, float fl, float fl1, void* stream) {
+  return classify_fuse(feat, logits, inst_proto, inst_flag, run_proto, run_flag, out, work, B, C, hw, CH, tau, pl, pl1, fl, fl1, 0, stream,
+                       true);
+}
+
 extern "C" int diga_proto_classify_fuse_frames(const void* feat, const float* logits, const float* inst_protos, const float* inst_flags,
                                                const float* run_protos, const float* run_flags, float* out, void* work, int nframes,
                                                int C, int hw, int CH, float tau, float pl, float pl1, float fl, float fl1, void* stream) {
   return classify_fuse(feat, logits, inst_protos, inst_flags, run_protos, run_flags, out, work, nframes, C, hw, CH, tau, pl, pl1, fl, fl1,
                        1, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same classifier for callers that cannot allocate (code under HIP-graph capture, tight serving loops,
+// harnesses that forbid hipMalloc): the work buffer of diga_proto_classify_fuse (prototype image + partial squared
+// distances) lives in a file-scope device array instead of a caller-supplied workspace.  No counterpart in the
+// reference.  Limits: B*hw <= DIGA_NOALLOC_MAX_PIXELS, CH <= DIGA_NOALLOC_MAX_CH.  Every device the library runs on
+// holds its own copy of the array (20.5 MiB) until the process ends.
+// ---------------------------------------------------------------------------------------------
+constexpr int64_t NOALLOC_BYTES =
+    (int64_t)DIGA_NOALLOC_MAX_CH * 64 * 4 + (int64_t)PCF_SPLIT * DIGA_NOALLOC_MAX_PIXELS * PCF_SLOTS * 4;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
+namespace {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[NOALLOC_MAX_DEVICES];      // per device: the DEVICE address of that device's copy of `scratch`
+
+// `scratch` in host code is only a handle for hipGetSymbolAddress, never a device address: resolve it once per
+// device (with that device current) and hand the kernels the resolved pointer.
+int scratch_for_current_device(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) {
+    diga_set_error("diga_proto_classify_fuse_noalloc: hipGetDevice failed or device index %d >= %d", dev, NOALLOC_MAX_DEVICES);
+    return DIGA_ELAUNCH;
+  }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+      diga_set_error("diga_proto_classify_fuse_noalloc: hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+      return DIGA_ELAUNCH;
+    }
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return DIGA_OK;
+}
+}  // namespace
+
+extern "C" int diga_proto_classify_fuse_noalloc(const void* feat, const float* logits, const float* inst_proto,
+                                                const float* inst_flag, const float* run_proto, const float* run_flag,
+                                                float* out, int B, int C, int hw, int CH, float tau, float pl, float pl1,
+                                                float fl, float fl1, void* stream) {
+  DIGA_CHECK_ARG(B > 0 && hw > 0 && CH > 0, "diga_proto_classify_fuse_noalloc: bad sizes");
+  DIGA_CHECK_ARG((int64_t)B * hw <= DIGA_NOALLOC_MAX_PIXELS && CH <= DIGA_NOALLOC_MAX_CH,
+                 "diga_proto_classify_fuse_noalloc: B*hw = %lld pixels x %d channels exceeds the static scratch (max %d pixels, %d "
+                 "channels): use diga_proto_classify_fuse with a caller-supplied workspace",
+                 (long long)B * hw, CH, DIGA_NOALLOC_MAX_PIXELS, DIGA_NOALLOC_MAX_CH);
+  DIGA_CHECK_ARG(diga_proto_classify_frames_work_bytes(1, (int64_t)B * hw, CH) <= NOALLOC_BYTES,
+                 "diga_proto_classify_fuse_noalloc: workspace plan exceeds the static scratch");
+  void* ptr = nullptr;
+  if (int e = scratch_for_current_device(&ptr)) return e;
+  // nothing has to be cleared: the transpose kernel writes the whole prototype image, the distance kernel every partial
+  // (all PCF_SLOTS slots of every pixel < P) the fuse kernel reads.  Calls that overlap on one GPU share the array: they race.
+  return classify_fuse(feat, logits, inst_proto, inst_flag, run_proto, run_flag, out, ptr, B, C, hw, CH, tau, pl, pl1, fl, fl1, 0, stream);
 }

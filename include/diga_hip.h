@@ -224,6 +224,21 @@ int diga_proto_classify_fuse_frames(const void* feat, const float* logits, const
                                     float* out, void* work, int nframes, int C, int hw, int CH, float tau,
                                     float pl, float pl1, float fl, float fl1, void* stream);
 
+/* diga_proto_classify_fuse (batch form, one prototype set) for callers that CANNOT ALLOCATE device memory -- code under
+ * HIP-graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  The
+ * workspace (prototype image + partial squared distances) is a file-scope device array inside the library, 20.5 MiB per
+ * GPU the library runs on, held until the process ends; the call allocates and frees nothing.
+ * Limits: B*hw <= DIGA_NOALLOC_MAX_PIXELS and CH <= DIGA_NOALLOC_MAX_CH, else DIGA_EINVAL with a message.
+ * The first call on a device resolves the array's device address (hipGetSymbolAddress; make that call outside stream
+ * capture).  All calls on one GPU share the array: calls that overlap on one GPU (two streams, two threads) race --
+ * serialise them.  Results are bit-identical to diga_proto_classify_fuse. */
+#define DIGA_NOALLOC_MAX_PIXELS 16384
+#define DIGA_NOALLOC_MAX_CH 2048
+int diga_proto_classify_fuse_noalloc(const void* feat, const float* logits, const float* inst_proto,
+                                     const float* inst_flag, const float* run_proto, const float* run_flag,
+                                     float* out, int B, int C, int hw, int CH, float tau, float pl, float pl1,
+                                     float fl, float fl1, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optional SAM extension (BASELINE.json north_star (2)).  NO counterpart in the reference: DIGA as
  * published has no connected-component step, the default path never calls these, and with respect to the
