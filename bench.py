@@ -110,21 +110,27 @@ def cpu_baseline(nframes_timed=10, H=512, W=1024):
                        f"confusion matrix), torch {torch.__version__} CPU")
 
 
-def miou_vs_reference(weights, dev, fif, nwin, autotune):
-    """The "mIoU delta vs ref" half of BASELINE.json's metric: the first frames of the synthetic batch-1 stream through the
+def miou_vs_reference(weights, dev, fif, nwin, autotune, seed=0):
+    """The "mIoU delta vs ref" half of BASELINE.json's metric: the first frames of a synthetic batch-1 stream through the
     SAME configuration the throughput is measured in (nwin windows of fif frames in flight), fresh prototypes, against the
-    reference's own mIoU-19/16/13 for those frames (tests/golden/net_stream.npz, written by oracle/gen_golden.py from the
-    reference source on CPU).  Bar: +-0.1 (north star)."""
+    reference's own mIoU-19/16/13 for those frames (tests/golden/net_stream.npz for frame seed 0, net_streams_ms.npz for
+    seeds 1..4; written by oracle/gen_golden.py from the reference source on CPU).  Bar: +-0.1 (north star) -- on the MEAN
+    over the streams: with bf16 activation storage one stream's delta is one draw of the rounding noise."""
     from diga_amd import synth
     from diga_amd.pipeline import StreamWindows
     from diga_amd.ttda_module import SegmentationMetric
-    path = os.path.join(ROOT, "tests", "golden", "net_stream.npz")
+    path = os.path.join(ROOT, "tests", "golden", "net_stream.npz" if seed == 0 else "net_streams_ms.npz")
     if not os.path.exists(path):
         return None
     with np.load(path, allow_pickle=False) as z:
-        ref = [float(v) for v in z["st_miou"]]
-        nframes = int(z["st_frames"])
-        ref_hist = z[f"st_{nframes - 1}_hist"]
+        if seed == 0:
+            ref = [float(v) for v in z["st_miou"]]
+            nframes = int(z["st_frames"])
+            ref_hist = z[f"st_{nframes - 1}_hist"]
+        else:
+            ref = [float(v) for v in z[f"ms{seed}_miou"]]
+            nframes = int(z["ms_frames"])
+            ref_hist = z[f"ms{seed}_hist"]
     k = min(fif, nframes)
     nw = nwin if k * nwin <= nframes else 1
     H, W = 512, 1024
@@ -141,7 +147,7 @@ def miou_vs_reference(weights, dev, fif, nwin, autotune):
             per_step = k
         wins = []
         for w in range(nw):
-            xy = [synth.synth_frame(t + w * k + j, 1, H, W) for j in range(k)]
+            xy = [synth.synth_frame(t + w * k + j, 1, H, W, seed=seed) for j in range(k)]
             wins.append((torch.from_numpy(np.concatenate([a for a, _ in xy])).to(dev),
                          torch.from_numpy(np.concatenate([b for _, b in xy])).to(dev)))
         sw.step(wins, CFG)
@@ -151,7 +157,7 @@ def miou_vs_reference(weights, dev, fif, nwin, autotune):
     hist = sw.engines[0].hist.reshape(19, 19).cpu()
     m.add_counts(hist)
     got = [float(m.compute()), float(m.compute_iou("16")), float(m.compute_iou("13"))]
-    return {"frames": nframes, "miou19_16_13": [round(v, 4) for v in got], "reference": [round(v, 4) for v in ref],
+    return {"frames": nframes, "frame_seed": seed, "miou19_16_13": [round(v, 4) for v in got], "reference": [round(v, 4) for v in ref],
             "delta": [round(a - b, 4) for a, b in zip(got, ref)], "bar": 0.1,
             "confusion_entries_differing": int((hist.numpy() != ref_hist).sum()),
             "pixels_moved": int(np.abs(hist.numpy() - ref_hist).sum() // 2),

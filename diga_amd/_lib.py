@@ -20,7 +20,7 @@ class ConvDesc(C.Structure):
                 ("stride", C.c_int32), ("ntaps", C.c_int32),
                 ("dy", C.c_int16 * MAX_TAPS), ("dx", C.c_int16 * MAX_TAPS),
                 ("cout_pad", C.c_int32), ("splitk", C.c_int32),
-                ("out_f32", C.c_int32), ("tile", C.c_int32)]
+                ("out_f32", C.c_int32), ("tile", C.c_int32), ("nplanes", C.c_int32)]
 
 
 class DigaError(RuntimeError):
@@ -35,6 +35,8 @@ SIGNATURES = {
     "diga_last_error_string": (C.c_char_p, []),
     "diga_conv_stat_units": (_i, [C.POINTER(ConvDesc)]),
     "diga_conv_igemm_bf16": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "diga_conv_dam_ticket_words": (_i, [C.POINTER(ConvDesc)]),
+    "diga_conv_igemm_bf16_dam": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "diga_conv_igemm_bf16_apply": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "diga_stem_conv7x7s2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "diga_bn_finalize": (_i, [_vp, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
@@ -66,6 +68,14 @@ SIGNATURES = {
     "diga_upsample_argmax_hist_frames": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "diga_preprocess_image": (_i, [_vp, _i, _vp, _i, _i, _i, _d, _d, _d, _i, _vp]),
     "diga_map_labels": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _vp]),
+    "diga_stem_conv7x7s2_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "diga_bn_apply_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "diga_bn_relu_maxpool_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "diga_split_planes_f32": (_i, [_vp, _vp, _i, _i64, _vp]),
+    "diga_proto_pool_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "diga_proto_classify_fuse_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp]),
+    "diga_nchw_f32_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "diga_nhwc_f32_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "diga_nhwc_bf16_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "diga_nchw_f32_to_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
 }

@@ -4,24 +4,14 @@
 //   diga_bn_apply         -> y = relu(raw*scale + shift (+ residual))   (HBM/L2-bound elementwise)
 //   diga_bn_relu_maxpool  -> the stem's bn1 + ReLU + ceil-mode max pool in one pass
 #include "common.h"
+#include "dam_affine.h"
 
 namespace {
 
 // Slab = [unit][2 (sum, sumsq)][C]; units are sample-major, `ups` units per sample.
 // Block = 64 channels (lanes, coalesced slab reads) x FIN_PH unit phases (waves).  Phase w sums units
 // u0+w, u0+w+FIN_PH, ... of a unit range in fp64; the phases are then combined through LDS in fixed order
-// -> deterministic, and a sample's result does not depend on which batch it is part of.
-constexpr int FIN_PH = 16;
-
-__device__ __forceinline__ void slab_range_sums(const float* __restrict__ slab, int u0, int u1, int C, int c, int ph, double* s) {
-  s[0] = s[1] = 0;
-#pragma unroll 4
-  for (int u = u0 + ph; u < u1; u += FIN_PH) {
-    const float* q = slab + (size_t)u * 2 * C + c;
-    s[0] += (double)q[0];
-    s[1] += (double)q[C];
-  }
-}
+// -> deterministic, and a sample's result does not depend on which batch it is part of (dam_affine.h).
 
 // sums of group A (units [a0,a1)) and group B (units [a1,b1)) -> s[4] valid in phase 0 of the block
 __device__ __forceinline__ void slab_group_sums(const float* __restrict__ slab, int a0, int a1, int b1, int C, int c, bool live,
@@ -42,30 +32,6 @@ __device__ __forceinline__ void slab_group_sums(const float* __restrict__ slab, 
     for (int w = 0; w < FIN_PH; ++w) v += red[w][k][lane];
     s[k] = v;
   }
-}
-
-// group sums (fp64) -> lambda-mixed scale/shift of channel c  (ttda:313-343)
-__device__ __forceinline__ void dam_affine_from_sums(const double* s, int c, double n_a, double n_b, const float* __restrict__ rmean,
-                                                     const float* __restrict__ rvar, const float* __restrict__ weight,
-                                                     const float* __restrict__ bias, float lam, float eps,
-                                                     float* __restrict__ scale, float* __restrict__ shift) {
-  const double K = (double)rmean[c];
-  const double ma = s[0] / n_a;
-  float mean_cur = (float)(K + ma);
-  float var_cur = (float)(s[1] / n_a - ma * ma);
-  if (n_b > 0) {
-    const double mb = s[2] / n_b;
-    const float mean_b = (float)(K + mb);
-    const float var_b = (float)(s[3] / n_b - mb * mb);
-    mean_cur = (mean_cur + mean_b) / 2.f;   // ttda:316-317 (fp32)
-    var_cur = (var_cur + var_b) / 2.f;
-  }
-  const float oml = 1.f - lam;              // fp32 subtraction, as the reference's tensor op (ttda:335)
-  const float mean = lam * rmean[c] + oml * mean_cur;
-  const float var = lam * rvar[c] + oml * var_cur;
-  const float sc = weight[c] / sqrtf(var + eps);
-  scale[c] = sc;
-  shift[c] = bias[c] - mean * sc;
 }
 
 __global__ __launch_bounds__(64 * FIN_PH) void bn_finalize_kernel(const float* __restrict__ slab, int ups, int nsamples, int a_samples,
@@ -282,6 +248,104 @@ __global__ void bn_apply_nchw_kernel(const float* __restrict__ x, const float* _
   out[i] = fmaf(x[i], scale[c], shift[c]);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Verification mode (fp32 activations carried as bf16 operand planes, see conv_igemm.hip): the same three elementwise
+// stages on fp32 data.  An fp32 value is stored for the next conv as nplanes bf16 planes p0 = bf16(y), p1 = bf16(y - p0),
+// p2 = bf16(y - p0 - p1) (the subtractions are exact in fp32), plus an fp32 copy for residuals / SAM.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_planes_store(float y, unsigned short* __restrict__ planes, int nplanes, size_t plane_stride,
+                                                   size_t idx) {
+  float r = y;
+  for (int q = 0; q < nplanes; ++q) {
+    const unsigned short b = f32_to_bf16_bits(r);
+    planes[q * plane_stride + idx] = b;
+    r -= bf16_bits_to_f32(b);
+  }
+}
+
+// MODE as bn_apply_kernel; thread = one element (this path is about exactness, not speed)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_apply_f32_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ res,
+                                                           const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                           float* __restrict__ out_f32, unsigned short* __restrict__ planes,
+                                                           int nplanes, int64_t total, int C, int relu) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  float y = fmaf(raw[i], scale[c], shift[c]);
+  if (MODE == 1) y += res[i];
+  if (MODE == 2) y += fmaf(res[i], rscale[c], rshift[c]);
+  if (relu) y = fmaxf(y, 0.f);
+  if (out_f32) out_f32[i] = y;
+  if (planes) split_planes_store(y, planes, nplanes, (size_t)total, (size_t)i);
+}
+
+__global__ __launch_bounds__(256) void bn_relu_maxpool_f32_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, float* __restrict__ out_f32,
+                                                                  unsigned short* __restrict__ planes, int nplanes, int B, int H,
+                                                                  int W, int C, int Ho, int Wo) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * Ho * Wo * C;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  int64_t pix = idx / C;
+  const int ow = (int)(pix % Wo);
+  pix /= Wo;
+  const int oh = (int)(pix % Ho), n = (int)(pix / Ho);
+  const float sc = scale[c], sh = shift[c];
+  float best = -INFINITY;
+  for (int kh = 0; kh < 3; ++kh) {
+    const int ih = oh * 2 - 1 + kh;
+    if ((unsigned)ih >= (unsigned)H) continue;
+    for (int kw = 0; kw < 3; ++kw) {
+      const int iw = ow * 2 - 1 + kw;
+      if ((unsigned)iw >= (unsigned)W) continue;
+      best = fmaxf(best, fmaxf(fmaf(raw[((int64_t)(n * H + ih) * W + iw) * C + c], sc, sh), 0.f));
+    }
+  }
+  if (out_f32) out_f32[idx] = best;
+  if (planes) split_planes_store(best, planes, nplanes, (size_t)total, (size_t)idx);
+}
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ planes,
+                                                           int nplanes, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) split_planes_store(x[i], planes, nplanes, (size_t)n, (size_t)i);
+}
+
+// [B][C][HW] fp32 <-> [B][HW][C] fp32 through a 32x32 LDS tile
+__global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int C) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, p = p0 + tx;
+    t[i][tx] = (p < HW && c < C) ? in[((size_t)b * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int p = p0 + i, c = c0 + tx;
+    if (p < HW && c < C) out[((size_t)b * HW + p) * C + c] = t[tx][i];
+  }
+}
+
+__global__ void nhwc_to_nchw_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int C) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int p = p0 + i, c = c0 + tx;
+    t[i][tx] = (p < HW && c < C) ? in[((size_t)b * HW + p) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, p = p0 + tx;
+    if (p < HW && c < C) out[((size_t)b * C + c) * HW + p] = t[tx][i];
+  }
+}
+
 }  // namespace
 
 extern "C" int diga_bn_finalize(const float* slab, int units_per_sample, int nsamples, int a_samples, int per_sample, int C,
@@ -399,5 +463,64 @@ extern "C" int diga_bn_apply_nchw_f32(const float* x, const float* scale, const 
   hipLaunchKernelGGL(bn_apply_nchw_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out, C, HW,
                      total);
   DIGA_CHECK_LAUNCH("diga_bn_apply_nchw_f32");
+  return DIGA_OK;
+}
+
+extern "C" int diga_bn_apply_f32(const float* raw, const float* scale, const float* shift, const float* res, const float* res_scale,
+                                 const float* res_shift, float* out_f32, void* out_planes, int nplanes, int64_t M, int C, int relu,
+                                 void* stream) {
+  DIGA_CHECK_ARG(raw && scale && shift && (out_f32 || out_planes), "diga_bn_apply_f32: NULL pointer");
+  DIGA_CHECK_ARG(M > 0 && C > 0 && (!out_planes || (nplanes >= 1 && nplanes <= 3)), "diga_bn_apply_f32: bad sizes / nplanes");
+  DIGA_CHECK_ARG((res_scale == nullptr) == (res_shift == nullptr), "diga_bn_apply_f32: res_scale/res_shift go together");
+  DIGA_CHECK_ARG(res != nullptr || res_scale == nullptr, "diga_bn_apply_f32: residual affine without residual");
+  const int64_t total = M * C;
+  const dim3 grid(cdiv(total, 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short* pl = (unsigned short*)out_planes;
+  if (!res)
+    hipLaunchKernelGGL(bn_apply_f32_kernel<0>, grid, block, 0, st, raw, scale, shift, res, res_scale, res_shift, out_f32, pl, nplanes, total, C, relu);
+  else if (!res_scale)
+    hipLaunchKernelGGL(bn_apply_f32_kernel<1>, grid, block, 0, st, raw, scale, shift, res, res_scale, res_shift, out_f32, pl, nplanes, total, C, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_f32_kernel<2>, grid, block, 0, st, raw, scale, shift, res, res_scale, res_shift, out_f32, pl, nplanes, total, C, relu);
+  DIGA_CHECK_LAUNCH("diga_bn_apply_f32");
+  return DIGA_OK;
+}
+
+extern "C" int diga_bn_relu_maxpool_f32(const float* raw, const float* scale, const float* shift, float* out_f32, void* out_planes,
+                                        int nplanes, int B, int H, int W, int C, int Ho, int Wo, void* stream) {
+  DIGA_CHECK_ARG(raw && scale && shift && (out_f32 || out_planes), "diga_bn_relu_maxpool_f32: NULL pointer");
+  DIGA_CHECK_ARG(B > 0 && H > 1 && W > 1 && C > 0 && (!out_planes || (nplanes >= 1 && nplanes <= 3)), "diga_bn_relu_maxpool_f32: bad dims");
+  auto osz = [](int L) {
+    int o = (L + 2 - 3 + 1) / 2 + 1;
+    if ((o - 1) * 2 >= L + 1) --o;
+    return o;
+  };
+  DIGA_CHECK_ARG(Ho == osz(H) && Wo == osz(W), "diga_bn_relu_maxpool_f32: output %dx%d does not match ceil-mode pooling of %dx%d", Ho, Wo, H, W);
+  const int64_t total = (int64_t)B * Ho * Wo * C;
+  hipLaunchKernelGGL(bn_relu_maxpool_f32_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, out_f32,
+                     (unsigned short*)out_planes, nplanes, B, H, W, C, Ho, Wo);
+  DIGA_CHECK_LAUNCH("diga_bn_relu_maxpool_f32");
+  return DIGA_OK;
+}
+
+extern "C" int diga_split_planes_f32(const float* x, void* planes, int nplanes, int64_t n, void* stream) {
+  DIGA_CHECK_ARG(x && planes && n > 0 && nplanes >= 1 && nplanes <= 3, "diga_split_planes_f32: bad argument");
+  hipLaunchKernelGGL(split_planes_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)planes, nplanes, n);
+  DIGA_CHECK_LAUNCH("diga_split_planes_f32");
+  return DIGA_OK;
+}
+
+extern "C" int diga_nchw_f32_to_nhwc_f32(const float* in, float* out, int B, int HW, int C, void* stream) {
+  DIGA_CHECK_ARG(in && out && B > 0 && HW > 0 && C > 0, "diga_nchw_f32_to_nhwc_f32: bad argument");
+  hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, HW, C);
+  DIGA_CHECK_LAUNCH("diga_nchw_f32_to_nhwc_f32");
+  return DIGA_OK;
+}
+
+extern "C" int diga_nhwc_f32_to_nchw_f32(const float* in, float* out, int B, int HW, int C, void* stream) {
+  DIGA_CHECK_ARG(in && out && B > 0 && HW > 0 && C > 0, "diga_nhwc_f32_to_nchw_f32: bad argument");
+  hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, HW, C);
+  DIGA_CHECK_LAUNCH("diga_nhwc_f32_to_nchw_f32");
   return DIGA_OK;
 }

@@ -6,9 +6,8 @@
 //     n = output channel                           N = Cout
 //     k = (ci chunk, tap, ci % 64)                 K = ntaps*Cin, one 64-wide K step = one tap of one 64-channel chunk
 //   A is gathered on the fly (im2col never materialised): row m, tap t reads the 128-byte channel
-//   slab of input pixel (oh*stride+dy[t], ow*stride+dx[t]) or zeros outside the image.  Out-of-image
-//   and out-of-range rows are produced by the buffer-descriptor range check (offset >= num_records
-//   returns 0), so the gather is branch-free.
+//   slab of input pixel (oh*stride+dy[t], ow*stride+dx[t]); out-of-image taps and rows beyond the sample read
+//   a 16-byte zero page instead (a select on the source address, so the gather stays branch-free).
 //
 // Block = 4 or 8 waves (WM x WN), tile BM x BN x 64.  The K loop is an S-deep LDS ring filled by LDS-DMA
 // (global_load_lds_dwordx4, no register staging) with counted vmcnt and one raw s_barrier per K step.
@@ -23,7 +22,15 @@
 // accumulators, one "unit" per 32-row MFMA block (columns live on lanes, rows in registers: 16 adds + one
 // cross-half shuffle), written to a slab that diga_bn_finalize sums in fixed order (deterministic, no atomics,
 // independent of the tile shape);  (2) the raw output is staged through LDS and stored as 16-byte NHWC rows.
+//
+// Verification mode (desc.nplanes = 2 / 3): the SAME kernel with every operand given as 2 / 3 bf16 planes whose sum
+// is the fp32 value (hi = bf16(x), lo = bf16(x - hi), ...).  The K loop then runs over the operand-plane products
+// (a, b) with a + b < nplanes -- 3 terms ("bf16x3", ~2^-17 per product) or 6 terms ("bf16x6", fp32-grade) -- as extra
+// K ranges, small terms first, into the same fp32 accumulators; output and statistics are taken in fp32.  This is the
+// fp32-exact path the end-to-end parity gate runs (the reference is fp32 end to end, ttda:1634-1645).
 #include "common.h"
+#include "dam_affine.h"
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -40,7 +47,20 @@ struct ConvKParams {
   int ep_affine_stride, ep_relu;
   int H, W, Cin, Ho, Wo, Cout, stride, ntaps;
   int M, K, cout_pad, hw, tiles_per_sample, units_per_sample, nk_total, nk_per_split, mtiles, ntiles_n;
-  unsigned in_bytes, wgt_bytes;
+  // operand planes (verification mode): nk_total = nterms * nk_plane K steps; term t multiplies plane term_ab[t] & 0xff of
+  // the input (in + plane * in_plane_stride elements) with plane term_ab[t] >> 8 of the weights.  nterms = 1: plain bf16.
+  int nterms, nk_plane, in_plane_stride, wgt_plane_stride;
+  int term_ab[6];
+  // fused DAM finalize (diga_conv_igemm_bf16_dam): the LAST tile to finish of each (sample, N tile) group reduces that
+  // sample's slab columns [n0, n0 + BN) exactly as diga_bn_finalize(per_sample) does and writes scale / shift.
+  unsigned* fin_ticket;      // NULL = off; [samples * ntiles_n] counters, zero before the launch, left zero by it
+  const float* fin_rvar;     // running_var, weight, bias [Cout] (running_mean = shift)
+  const float* fin_weight;
+  const float* fin_bias;
+  float* fin_scale;          // [samples][Cout]
+  float* fin_shift;
+  float fin_lam, fin_eps;
+  double fin_n;              // elements per sample and channel
   int dydx[DIGA_MAX_TAPS];   // (dy << 16) | (dx & 0xffff): 32-bit so that the uniform per-tap lookup is a scalar load
 };
 
@@ -55,11 +75,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Epilogue modes: 0 = bf16 output + statistics (the trunk), 1 = fp32 output (head GEMM / split-K partials),
 // 2 = bf16 output only, 3 = statistics only (nothing stored: pass 1 of a recomputed conv3), 4 = fused DAM apply:
 // out = relu(acc*scale[c] + shift[c] + residual) in bf16, straight from the fp32 accumulators (pass 2).
-enum { EPI_BF16_STATS = 0, EPI_F32 = 1, EPI_BF16 = 2, EPI_STATS_ONLY = 3, EPI_FUSED_APPLY = 4 };
+// 5 = fp32 output + statistics (verification mode: nothing is rounded to bf16 between the accumulators and the next stage).
+enum { EPI_BF16_STATS = 0, EPI_F32 = 1, EPI_BF16 = 2, EPI_STATS_ONLY = 3, EPI_FUSED_APPLY = 4, EPI_F32_STATS = 5 };
 
 template <int BM, int BN, int WM, int WN, int S, int BK, bool ILV, int EPI>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKParams p) {
-  constexpr bool OUT_F32 = EPI == EPI_F32, STATS = EPI == EPI_BF16_STATS || EPI == EPI_STATS_ONLY;
+  constexpr bool OUT_F32 = EPI == EPI_F32 || EPI == EPI_F32_STATS;
+  constexpr bool STATS = EPI == EPI_BF16_STATS || EPI == EPI_STATS_ONLY || EPI == EPI_F32_STATS;
   constexpr int NW = WM * WN, NTHR = 64 * NW;        // 4 or 8 waves
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -82,12 +104,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
   // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
   // run of logical tile ids (N tiles of one M tile share the gathered A rows in that XCD's L2).
   int bid = blockIdx.x;
-#ifndef DIGA_NO_XCD_REMAP
   {
     const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-#endif
   const int mtile = bid / p.ntiles_n, ntile = bid - mtile * p.ntiles_n;
   // M tiles never straddle samples: tile -> (sample, tile within the sample).  A sample's rows are tiled from
   // its own row 0, so its results (and its 32-row statistics units) do not depend on the batch it rides in.
@@ -106,8 +126,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
   // Wave w owns row groups w, w+NW, ... (rows RPI*(w + NW*i) + l/CPRW); those rows are fixed for the whole K loop.
   const int lrow = RPI * wave + lane / CPRW;
   const int cch = (lane % CPRW) ^ (BK == 64 ? (lrow >> 1) & 7 : (lrow >> 2) & 3);   // swz is i-invariant
-  const unsigned short* const in = reinterpret_cast<const unsigned short*>(p.in);
-  const unsigned short* const wgt = reinterpret_cast<const unsigned short*>(p.wgt);
+  // K steps [ks_begin, ks_end) of the launch's nterms * nk_plane: term = step / nk_plane picks the operand planes
+  int is_term = ks_begin / p.nk_plane;
+  int is_kin = ks_begin - is_term * p.nk_plane;                 // K step inside the term
+  const unsigned short* in = reinterpret_cast<const unsigned short*>(p.in) + (size_t)(p.term_ab[is_term] & 0xff) * p.in_plane_stride;
+  const unsigned short* wgt = reinterpret_cast<const unsigned short*>(p.wgt) + (size_t)(p.term_ab[is_term] >> 8) * p.wgt_plane_stride;
   const unsigned short* const zero = reinterpret_cast<const unsigned short*>(g_zero16);
   int pixoff[A_CH], ih0[A_CH], iw0[A_CH];
 #pragma unroll
@@ -134,10 +157,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
   // fetched one issue ahead (a scalar load whose latency would otherwise sit between the barrier and the DMAs).
   // K order = [channel chunk][tap][64]: the ntaps steps of one 64-channel chunk run back to back, so the taps'
   // overlapping pixel lines are re-read while they are still in L2 (a 3x3 tile touches ~3x, not 9x, its rows).
-  int is_ks = ks_begin;
   int is_chunk, is_tap;
   {
-    const int q = BK == 64 ? ks_begin : ks_begin >> 1;          // index of the 64-wide (chunk, tap) step
+    const int q = BK == 64 ? is_kin : is_kin >> 1;              // index of the 64-wide (chunk, tap) step
     is_chunk = q / p.ntaps;
     is_tap = q - is_chunk * p.ntaps;
   }
@@ -148,8 +170,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
   // both waves of a SIMD burst together and the MFMA pipe idles).
   auto issue_pieces = [&](int stage, auto lo_c, auto hi_c) {
     constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
-    const int kk = is_ks * BK;
-    const int c0 = is_chunk * 64 + (BK == 64 ? 0 : (is_ks & 1) * 32);
+    const int kk = is_kin * BK;
+    const int c0 = is_chunk * 64 + (BK == 64 ? 0 : (is_kin & 1) * 32);
     const int dy = is_dd >> 16, dx = (int)(short)(is_dd & 0xffff);
     const int tapoff = (dy * p.W + dx) * p.Cin + c0;
     unsigned char* const dA = smem + stage * STAGE_BYTES + wave * 1024;
@@ -168,8 +190,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     }
   };
   auto advance_next = [&]() {
-    ++is_ks;
-    if (BK == 64 || !(is_ks & 1)) {
+    if (++is_kin == p.nk_plane) {          // next operand-plane product (verification mode; never taken with nterms = 1)
+      is_kin = 0;
+      is_chunk = 0;
+      is_tap = 0;
+      is_dd = p.dydx[0];
+      if (++is_term < p.nterms) {
+        in = reinterpret_cast<const unsigned short*>(p.in) + (size_t)(p.term_ab[is_term] & 0xff) * p.in_plane_stride;
+        wgt = reinterpret_cast<const unsigned short*>(p.wgt) + (size_t)(p.term_ab[is_term] >> 8) * p.wgt_plane_stride;
+      }
+    } else if (BK == 64 || !(is_kin & 1)) {
       if (++is_tap == p.ntaps) {
         is_tap = 0;
         ++is_chunk;
@@ -221,17 +251,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
       for (int b = 0; b < NT; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(bB + b * 32 * ROWB + coff);
       if (ILV && more)                  // this group's share of the next K step's loads, in the shadow of the MFMAs below
         issue_pieces(fill, std::integral_constant<int, s * LPT / KS>{}, std::integral_constant<int, (s + 1) * LPT / KS>{});
-#ifdef DIGA_SETPRIO
-      __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
-#ifdef DIGA_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
     };
     ksub(std::integral_constant<int, 0>{});
     ksub(std::integral_constant<int, 1>{});
@@ -289,7 +313,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
           }
           t1 += __shfl_xor(t1, 32);
           t2 += __shfl_xor(t2, 32);
-          if (c < p.Cout) p.slab[(urow + hh) * p.Cout + c] = hh ? t2 : t1;
+          if (c < p.Cout) {
+            if (p.fin_ticket)      // read back inside this launch by another block, maybe on another XCD: write through
+              __hip_atomic_store(&p.slab[(urow + hh) * p.Cout + c], hh ? t2 : t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+              p.slab[(urow + hh) * p.Cout + c] = hh ? t2 : t1;
+          }
         }
       }
     }
@@ -365,6 +394,58 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
         __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(sC + row * BN + cc * 8), reinterpret_cast<u32x4*>(out + (size_t)(m_base + rem) * p.Cout + c));
     }
   }
+
+  if constexpr (STATS) {
+    if (p.fin_ticket) {
+      // ---- fused DAM finalize.  The XCDs' L2s are not coherent with each other inside a launch: this block's slab values went
+      // out as agent-scope write-through stores, it takes a ticket for its (sample, N tile) group, and the block that draws the
+      // last ticket reduces the group with agent-scope (L2-bypassing) loads: the arithmetic and the summation order are those
+      // of bn_finalize_kernel (dam_affine.h), so scale / shift are bit-identical to the two-launch form.
+      // (the slab stores above are agent-scope write-through stores when the finalize is fused: wait until they are performed.
+      // A release FENCE here writes the whole L2 back and an acquire fence invalidates it -- the L2 the other tiles' operand
+      // re-use lives on: measured 296 vs 708 frames/s.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                     // every thread's slab stores are released; the LDS staging tile is dead
+      int* s_last = reinterpret_cast<int*>(smem);
+      if (tid == 0) {
+        unsigned* tk = p.fin_ticket + n_img * p.ntiles_n + ntile;
+        const unsigned prev = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (unsigned)p.tiles_per_sample - 1u;
+        if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        *s_last = last;
+      }
+      __syncthreads();
+      const int last = *s_last;
+      __syncthreads();                     // s_last is read before the reduction overwrites the LDS
+      if (last) {
+        constexpr int PARTS = NTHR / BN;                        // threads per channel: 1..16, a power of two
+        static_assert(PARTS >= 1 && PARTS <= FIN_PH && FIN_PH % PARTS == 0, "phases are dealt evenly over a channel's threads");
+        double* red = reinterpret_cast<double*>(smem);          // [FIN_PH][2][BN]
+        const int u0 = n_img * p.units_per_sample, u1 = u0 + p.units_per_sample;
+        {
+          const int cl = tid % BN, part = tid / BN, c = n0 + cl;
+          for (int ph = part; ph < FIN_PH; ph += PARTS) {
+            double sm[2] = {0, 0};
+            if (c < p.Cout) slab_range_sums<true>(p.slab, u0, u1, p.Cout, c, ph, sm);
+            red[(ph * 2 + 0) * BN + cl] = sm[0];
+            red[(ph * 2 + 1) * BN + cl] = sm[1];
+          }
+        }
+        __syncthreads();
+        for (int cl = tid; cl < BN; cl += NTHR) {
+          const int c = n0 + cl;
+          if (c >= p.Cout) continue;
+          double sm[4] = {0, 0, 0, 0};
+          for (int w = 0; w < FIN_PH; ++w) {
+            sm[0] += red[(w * 2 + 0) * BN + cl];
+            sm[1] += red[(w * 2 + 1) * BN + cl];
+          }
+          dam_affine_from_sums(sm, c, p.fin_n, 0.0, p.shift, p.fin_rvar, p.fin_weight, p.fin_bias, p.fin_lam, p.fin_eps,
+                               p.fin_scale + (size_t)n_img * p.Cout, p.fin_shift + (size_t)n_img * p.Cout);
+        }
+      }
+    }
+  }
 }
 
 struct TileCfg {
@@ -411,24 +492,27 @@ template <int BM, int BN, int WM, int WN, int S, int BK = 64, bool ILV = false>
 int launch_cfg(const ConvKParams& p, int splitk, int epi, hipStream_t st) {
   constexpr int main_bytes = S * (BM + BN) * BK * 2;
   constexpr int epi_bytes = BM * BN * 2;
-  constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  constexpr int fin_bytes = FIN_PH * 2 * BN * 8;         // the fused finalize's fp64 phase sums
+  constexpr int smem01 = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  constexpr int smem = smem01 > fin_bytes ? smem01 : fin_bytes;
   dim3 grid(p.mtiles * p.ntiles_n, splitk), block(64 * WM * WN);
-  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance
 #define DIGA_EPI_KERNEL(E) conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, E>
-  if (!attr_set) {
+  static std::once_flag attr_once;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel instance (any thread may get here first)
+  std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_EPI_KERNEL(EPI_BF16_STATS)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_EPI_KERNEL(EPI_F32)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_EPI_KERNEL(EPI_BF16)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_EPI_KERNEL(EPI_STATS_ONLY)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_EPI_KERNEL(EPI_FUSED_APPLY)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_EPI_KERNEL(EPI_F32_STATS)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  });
   switch (epi) {
     case EPI_BF16_STATS: hipLaunchKernelGGL((DIGA_EPI_KERNEL(EPI_BF16_STATS)), grid, block, smem, st, p); break;
     case EPI_F32: hipLaunchKernelGGL((DIGA_EPI_KERNEL(EPI_F32)), grid, block, smem, st, p); break;
     case EPI_BF16: hipLaunchKernelGGL((DIGA_EPI_KERNEL(EPI_BF16)), grid, block, smem, st, p); break;
     case EPI_STATS_ONLY: hipLaunchKernelGGL((DIGA_EPI_KERNEL(EPI_STATS_ONLY)), grid, block, smem, st, p); break;
     case EPI_FUSED_APPLY: hipLaunchKernelGGL((DIGA_EPI_KERNEL(EPI_FUSED_APPLY)), grid, block, smem, st, p); break;
+    case EPI_F32_STATS: hipLaunchKernelGGL((DIGA_EPI_KERNEL(EPI_F32_STATS)), grid, block, smem, st, p); break;
     default: diga_set_error("diga_conv_igemm_bf16: bad epilogue mode %d", epi); return DIGA_EINVAL;
   }
 #undef DIGA_EPI_KERNEL
@@ -446,8 +530,11 @@ int validate(const diga_conv_desc* d, const char* who) {
   DIGA_CHECK_ARG((d->Ho - 1) * d->stride < d->H && (d->Wo - 1) * d->stride < d->W, "%s: output grid exceeds input", who);
   DIGA_CHECK_ARG(d->splitk >= 1 && (d->splitk == 1 || d->out_f32), "%s: splitk needs out_f32", who);
   DIGA_CHECK_ARG(d->out_f32 || d->Cout % 8 == 0, "%s: bf16 output needs Cout %% 8 == 0", who);
-  const int64_t in_bytes = (int64_t)d->B * d->H * d->W * d->Cin * 2;
-  const int64_t w_bytes = (int64_t)d->cout_pad * d->ntaps * d->Cin * 2;
+  DIGA_CHECK_ARG(d->nplanes >= 0 && d->nplanes <= 3, "%s: nplanes %d (0/1 = bf16 operands, 2/3 = split-operand verification mode)", who, d->nplanes);
+  DIGA_CHECK_ARG(d->nplanes <= 1 || (d->out_f32 && d->splitk == 1), "%s: operand planes need out_f32 and splitk == 1", who);
+  const int npl = d->nplanes > 1 ? d->nplanes : 1;
+  const int64_t in_bytes = (int64_t)npl * d->B * d->H * d->W * d->Cin * 2;
+  const int64_t w_bytes = (int64_t)npl * d->cout_pad * d->ntaps * d->Cin * 2;
   DIGA_CHECK_ARG(in_bytes < 0x7ffffff0ll && w_bytes < 0x7ffffff0ll, "%s: tensor exceeds the 2 GiB buffer range", who);
   const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
   DIGA_CHECK_ARG(M * d->cout_pad < 0x7fffffffll, "%s: output too large", who);
@@ -462,9 +549,16 @@ extern "C" int diga_conv_stat_units(const diga_conv_desc* d) {
 }
 
 namespace {
+struct FinArgs {               // fused DAM finalize (diga_conv_igemm_bf16_dam); ticket == nullptr: off
+  unsigned* ticket = nullptr;
+  const float *rvar = nullptr, *weight = nullptr, *bias = nullptr;
+  float *scale = nullptr, *shift = nullptr;
+  float lam = 0.f, eps = 0.f;
+};
+
 int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out, float* stat_slab, const float* stat_shift,
              int epi, const float* ep_scale, const float* ep_shift, const void* ep_res, int ep_affine_stride, int ep_relu,
-             void* stream) {
+             void* stream, const FinArgs& fin = FinArgs()) {
   const TileCfg* t = find_tile(d->tile ? d->tile : auto_tile(d));
   DIGA_CHECK_ARG(t != nullptr, "diga_conv_igemm_bf16: unknown tile id %d", d->tile);
   DIGA_CHECK_ARG(d->cout_pad % t->BN == 0, "diga_conv_igemm_bf16: cout_pad %d not a multiple of tile N %d", d->cout_pad, t->BN);
@@ -475,6 +569,9 @@ int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out
   p.slab = stat_slab;
   p.shift = stat_shift;
   p.ep_scale = ep_scale, p.ep_shift = ep_shift, p.ep_res = ep_res, p.ep_affine_stride = ep_affine_stride, p.ep_relu = ep_relu;
+  p.fin_ticket = fin.ticket, p.fin_rvar = fin.rvar, p.fin_weight = fin.weight, p.fin_bias = fin.bias;
+  p.fin_scale = fin.scale, p.fin_shift = fin.shift, p.fin_lam = fin.lam, p.fin_eps = fin.eps;
+  p.fin_n = (double)d->Ho * d->Wo;
   p.H = d->H, p.W = d->W, p.Cin = d->Cin, p.Ho = d->Ho, p.Wo = d->Wo, p.Cout = d->Cout;
   p.stride = d->stride, p.ntaps = d->ntaps;
   p.M = d->B * d->Ho * d->Wo;
@@ -483,12 +580,18 @@ int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out
   p.hw = d->Ho * d->Wo;
   p.tiles_per_sample = cdiv(p.hw, t->BM);
   p.units_per_sample = cdiv(p.hw, 32);
-  p.nk_total = p.K / t->BK;
+  // operand-plane products, smallest first: planes (a, b) with a + b < nplanes
+  static const int kTerms2[3] = {1 | (0 << 8), 0 | (1 << 8), 0};
+  static const int kTerms3[6] = {2 | (0 << 8), 0 | (2 << 8), 1 | (1 << 8), 1 | (0 << 8), 0 | (1 << 8), 0};
+  p.nterms = d->nplanes == 2 ? 3 : d->nplanes == 3 ? 6 : 1;
+  for (int i = 0; i < 6; ++i) p.term_ab[i] = d->nplanes == 2 ? kTerms2[i % 3] : d->nplanes == 3 ? kTerms3[i] : 0;
+  p.in_plane_stride = d->B * d->H * d->W * d->Cin;
+  p.wgt_plane_stride = d->cout_pad * p.K;
+  p.nk_plane = p.K / t->BK;
+  p.nk_total = p.nterms * p.nk_plane;
   p.nk_per_split = cdiv(p.nk_total, d->splitk);
   p.mtiles = d->B * p.tiles_per_sample;
   p.ntiles_n = d->cout_pad / t->BN;
-  p.in_bytes = (unsigned)((int64_t)d->B * d->H * d->W * d->Cin * 2);
-  p.wgt_bytes = (unsigned)((int64_t)d->cout_pad * p.K * 2);
   for (int i = 0; i < DIGA_MAX_TAPS; ++i) {
     const int dy = i < d->ntaps ? d->dy[i] : 0, dx = i < d->ntaps ? d->dx[i] : 0;
     p.dydx[i] = (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu));
@@ -541,8 +644,8 @@ extern "C" int diga_conv_igemm_bf16(const diga_conv_desc* d, const void* in, con
   DIGA_CHECK_ARG(in && wgt, "diga_conv_igemm_bf16: NULL tensor");
   DIGA_CHECK_ARG((stat_slab == nullptr) == (stat_shift == nullptr), "diga_conv_igemm_bf16: slab and shift go together");
   DIGA_CHECK_ARG(out || stat_slab, "diga_conv_igemm_bf16: no output and no statistics requested");
-  DIGA_CHECK_ARG(!(d->out_f32 && stat_slab), "diga_conv_igemm_bf16: statistics with fp32 split-K output are not supported");
-  const int epi = d->out_f32 ? EPI_F32 : (stat_slab ? (out ? EPI_BF16_STATS : EPI_STATS_ONLY) : EPI_BF16);
+  DIGA_CHECK_ARG(!(d->out_f32 && stat_slab) || (d->splitk == 1 && out), "diga_conv_igemm_bf16: statistics with fp32 output need splitk == 1 and an output");
+  const int epi = d->out_f32 ? (stat_slab ? EPI_F32_STATS : EPI_F32) : (stat_slab ? (out ? EPI_BF16_STATS : EPI_STATS_ONLY) : EPI_BF16);
   return run_conv(d, in, wgt, out, stat_slab, stat_shift, epi, nullptr, nullptr, nullptr, 0, 0, stream);
 }
 
@@ -550,7 +653,26 @@ extern "C" int diga_conv_igemm_bf16_apply(const diga_conv_desc* d, const void* i
                                           const float* shift, const void* res, int relu, int nsamples_affine, void* stream) {
   if (int e = validate(d, "diga_conv_igemm_bf16_apply")) return e;
   DIGA_CHECK_ARG(in && wgt && out && scale && shift && res, "diga_conv_igemm_bf16_apply: NULL tensor");
-  DIGA_CHECK_ARG(!d->out_f32 && d->splitk == 1, "diga_conv_igemm_bf16_apply: bf16 output, no split-K");
+  DIGA_CHECK_ARG(!d->out_f32 && d->splitk == 1 && d->nplanes <= 1, "diga_conv_igemm_bf16_apply: bf16 output, no split-K, no operand planes");
   DIGA_CHECK_ARG(nsamples_affine == 0 || nsamples_affine == d->B, "diga_conv_igemm_bf16_apply: nsamples_affine must be 0 or B");
   return run_conv(d, in, wgt, out, nullptr, nullptr, EPI_FUSED_APPLY, scale, shift, res, nsamples_affine ? d->Cout : 0, relu, stream);
+}
+
+extern "C" int diga_conv_dam_ticket_words(const diga_conv_desc* d) {
+  if (validate(d, "diga_conv_dam_ticket_words") != DIGA_OK) return DIGA_EINVAL;
+  return d->B * (d->cout_pad / 32);          // one counter per (sample, N tile); the narrowest N tile is 32 channels
+}
+
+extern "C" int diga_conv_igemm_bf16_dam(const diga_conv_desc* d, const void* in, const void* wgt, void* out, float* stat_slab,
+                                        const float* running_mean, const float* running_var, const float* weight, const float* bias,
+                                        float lam, float eps, float* scale, float* shift, uint32_t* ticket, void* stream) {
+  if (int e = validate(d, "diga_conv_igemm_bf16_dam")) return e;
+  DIGA_CHECK_ARG(in && wgt && stat_slab && running_mean && running_var && weight && bias && scale && shift && ticket,
+                 "diga_conv_igemm_bf16_dam: NULL pointer");
+  DIGA_CHECK_ARG(d->splitk == 1 && (d->out_f32 == 0 || out), "diga_conv_igemm_bf16_dam: splitk == 1; fp32 output needs a buffer");
+  const int epi = d->out_f32 ? EPI_F32_STATS : (out ? EPI_BF16_STATS : EPI_STATS_ONLY);
+  FinArgs fin;
+  fin.ticket = ticket, fin.rvar = running_var, fin.weight = weight, fin.bias = bias, fin.scale = scale, fin.shift = shift;
+  fin.lam = lam, fin.eps = eps;
+  return run_conv(d, in, wgt, out, stat_slab, running_mean, epi, nullptr, nullptr, nullptr, 0, 0, stream, fin);
 }

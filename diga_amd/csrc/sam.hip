@@ -160,7 +160,16 @@ __global__ __launch_bounds__(64) void proto_index_kernel(const int32_t* __restri
   if (lane == 0) counts[s * C + c] = count;
 }
 
-__global__ __launch_bounds__(256) void proto_pool_kernel(const unsigned short* __restrict__ feat, const int32_t* __restrict__ idx,
+// 8 consecutive channels of one feature row as fp32: bf16 features (the product path) or fp32 features (the verification
+// mode and the helper API called with arbitrary fp32 tensors, as the reference computes, ttda:1788-1805)
+__device__ __forceinline__ void load_row8(const unsigned short* p, float* f) { unpack_bf16x8(*reinterpret_cast<const u32x4*>(p), f); }
+__device__ __forceinline__ void load_row8(const float* p, float* f) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  f[0] = a[0], f[1] = a[1], f[2] = a[2], f[3] = a[3], f[4] = b[0], f[5] = b[1], f[6] = b[2], f[7] = b[3];
+}
+
+template <typename FT>
+__global__ __launch_bounds__(256) void proto_pool_kernel(const FT* __restrict__ feat, const int32_t* __restrict__ idx,
                                                          const int32_t* __restrict__ counts, int64_t P, int C, int CH, int CS,
                                                          int JC, float* __restrict__ partial, int nsets) {
   const int j = blockIdx.x, c = blockIdx.y, s = blockIdx.z;      // s = frame * nsets + set: every frame has its own features
@@ -176,21 +185,19 @@ __global__ __launch_bounds__(256) void proto_pool_kernel(const unsigned short* _
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
     int q = beg;
-    for (; q + 8 <= end; q += 8) {        // 8 independent 16-byte row reads in flight per lane
-      u32x4 r[8];
+    for (; q + 8 <= end; q += 8) {        // 8 independent row reads in flight per lane
+      float f[8][8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) r[u] = *reinterpret_cast<const u32x4*>(feat + (size_t)list[q + u] * CH + ch0);
+      for (int u = 0; u < 8; ++u) load_row8(feat + (size_t)list[q + u] * CH + ch0, f[u]);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        float f[8];
-        unpack_bf16x8(r[u], f);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += f[i];
+        for (int i = 0; i < 8; ++i) acc[i] += f[u][i];
       }
     }
     for (; q < end; ++q) {
       float f[8];
-      unpack_bf16x8(*reinterpret_cast<const u32x4*>(feat + (size_t)list[q] * CH + ch0), f);
+      load_row8(feat + (size_t)list[q] * CH + ch0, f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] += f[i];
     }
@@ -355,7 +362,8 @@ __global__ void proto_transpose_kernel(const float* __restrict__ inst_proto, con
   protoT[e] = v;
 }
 
-__global__ __launch_bounds__(128) void proto_dist_kernel(const unsigned short* __restrict__ feat, const float* __restrict__ protoT,
+template <typename FT>
+__global__ __launch_bounds__(128) void proto_dist_kernel(const FT* __restrict__ feat, const float* __restrict__ protoT,
                                                          float* __restrict__ work, int64_t P, int CH, int ch_per_split, int hw,
                                                          int bps, int64_t proto_set_stride) {
   __shared__ __attribute__((aligned(16))) float sf[64][PCF_PITCH];   // [ch][px]
@@ -374,13 +382,18 @@ __global__ __launch_bounds__(128) void proto_dist_kernel(const unsigned short* _
     for (int k = 0; k < 5; ++k) acc[i][k] = f32x2{0.f, 0.f};
   // the next chunk's global data (4 feature octets + 8 prototype float4 per thread) is fetched into registers while
   // the current chunk is being reduced, so its latency is off the critical path
-  u32x4 fr[4];
+  float fr[4][8];
   f32x4 pr[8];
   auto fetch = [&](int ch0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {            // feature tile: 64 px x 8 octets, 4 per thread; 8 lanes read one 128-B row
+    for (int j = 0; j < 4; ++j) {            // feature tile: 64 px x 8 octets, 4 per thread; 8 lanes read one row's 64 channels
       const int id = tid + 128 * j, r = id >> 3, o = id & 7;
-      fr[j] = pix0 + r < hw ? *reinterpret_cast<const u32x4*>(feat + (size_t)(p0 + r) * CH + ch0 + o * 8) : u32x4{0u, 0u, 0u, 0u};
+      if (pix0 + r < hw) {
+        load_row8(feat + (size_t)(p0 + r) * CH + ch0 + o * 8, fr[j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fr[j][i] = 0.f;
+      }
     }
     const f32x4* src = reinterpret_cast<const f32x4*>(protoT + (size_t)ch0 * 64);   // prototype image: straight 16 KB copy
 #pragma unroll
@@ -392,10 +405,8 @@ __global__ __launch_bounds__(128) void proto_dist_kernel(const unsigned short* _
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int id = tid + 128 * j, r = id >> 3, o = id & 7;
-      float f[8];
-      unpack_bf16x8(fr[j], f);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sf[o * 8 + i][r] = f[i];
+      for (int i = 0; i < 8; ++i) sf[o * 8 + i][r] = fr[j][i];
     }
     {
       f32x4* dst = reinterpret_cast<f32x4*>(&spr[0][0][0]);
@@ -559,8 +570,9 @@ extern "C" int64_t diga_proto_pool_work_bytes(int nsets, int64_t P, int C, int C
   return diga_proto_pool_frames_work_bytes(1, nsets, P, C, CH);
 }
 
-extern "C" int diga_proto_pool_frames(const void* feat, const int32_t* labels, int nframes, int nsets, int64_t P, int C, int CH,
-                                      void* work, float* sums, int32_t* counts, void* stream) {
+namespace {
+int pool_frames(const void* feat, bool feat_f32, const int32_t* labels, int nframes, int nsets, int64_t P, int C, int CH, void* work,
+                float* sums, int32_t* counts, void* stream) {
   DIGA_CHECK_ARG(feat && labels && work && sums && counts, "diga_proto_pool: NULL pointer");
   DIGA_CHECK_ARG(nframes >= 1 && nframes <= 4096 && nsets >= 1 && nsets <= 2 && P > 0 && P < (1ll << 31) && C > 0 &&
                      C <= DIGA_NUM_CLASSES_MAX && CH > 0 && CH % 8 == 0 && (int64_t)nframes * nsets * C <= 65535,
@@ -571,12 +583,27 @@ extern "C" int diga_proto_pool_frames(const void* feat, const int32_t* labels, i
   float* partial = (float*)((char*)work + pp.idx_bytes);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(proto_index_kernel, dim3(C, ns), dim3(64), 0, st, labels, P, C, idx, counts);
-  hipLaunchKernelGGL(proto_pool_kernel, dim3(pp.JC, C, ns), dim3(256), 0, st, (const unsigned short*)feat, idx, counts, P, C, CH,
-                     pp.CS, pp.JC, partial, nsets);
+  if (feat_f32)
+    hipLaunchKernelGGL(proto_pool_kernel<float>, dim3(pp.JC, C, ns), dim3(256), 0, st, (const float*)feat, idx, counts, P, C, CH,
+                       pp.CS, pp.JC, partial, nsets);
+  else
+    hipLaunchKernelGGL(proto_pool_kernel<unsigned short>, dim3(pp.JC, C, ns), dim3(256), 0, st, (const unsigned short*)feat, idx,
+                       counts, P, C, CH, pp.CS, pp.JC, partial, nsets);
   hipLaunchKernelGGL(proto_reduce_kernel, dim3(cdiv(CH, 256), ns * C), dim3(256), 0, st, partial, counts, C, CH, pp.CS, pp.JC,
                      sums);
   DIGA_CHECK_LAUNCH("diga_proto_pool");
   return DIGA_OK;
+}
+}  // namespace
+
+extern "C" int diga_proto_pool_frames(const void* feat, const int32_t* labels, int nframes, int nsets, int64_t P, int C, int CH,
+                                      void* work, float* sums, int32_t* counts, void* stream) {
+  return pool_frames(feat, false, labels, nframes, nsets, P, C, CH, work, sums, counts, stream);
+}
+
+extern "C" int diga_proto_pool_f32(const float* feat, const int32_t* labels, int nsets, int64_t P, int C, int CH, void* work,
+                                   float* sums, int32_t* counts, void* stream) {
+  return pool_frames(feat, true, labels, 1, nsets, P, C, CH, work, sums, counts, stream);
 }
 
 extern "C" int diga_proto_pool(const void* feat, const int32_t* labels, int nsets, int64_t P, int C, int CH, void* work,
@@ -622,7 +649,7 @@ extern "C" int64_t diga_proto_classify_work_bytes(int64_t P, int CH) { return di
 namespace {
 int classify_fuse(const void* feat, const float* logits, const float* inst_proto, const float* inst_flag, const float* run_proto,
                   const float* run_flag, float* out, void* work, int B, int C, int hw, int CH, float tau, float pl, float pl1, float fl,
-                  float fl1, int per_sample, void* stream) {
+                  float fl1, int per_sample, void* stream, bool feat_f32 = false) {
   DIGA_CHECK_ARG(feat && logits && inst_proto && inst_flag && run_proto && run_flag && out && work, "diga_proto_classify_fuse: NULL pointer");
   DIGA_CHECK_ARG(B > 0 && hw > 0 && C > 0 && 2 * C <= PCF_SLOTS && CH > 0 && CH % 64 == 0,
                  "diga_proto_classify_fuse: bad sizes (C <= 20, CH %% 64 == 0)");
@@ -637,8 +664,12 @@ int classify_fuse(const void* feat, const float* logits, const float* inst_proto
   DIGA_CHECK_ARG((int64_t)B * bps < (1ll << 31), "diga_proto_classify_fuse: too many pixels");
   partial = protoT + (size_t)nsets * CH * 64;
   hipLaunchKernelGGL(proto_transpose_kernel, dim3(cdiv(CH * 64, 256), nsets), dim3(256), 0, st, inst_proto, run_proto, protoT, C, CH);
-  hipLaunchKernelGGL(proto_dist_kernel, dim3(B * bps, nsplit), dim3(128), 0, st, (const unsigned short*)feat, protoT, partial, P, CH,
-                     CH / nsplit, hw, bps, per_sample ? (int64_t)CH * 64 : 0);
+  if (feat_f32)
+    hipLaunchKernelGGL(proto_dist_kernel<float>, dim3(B * bps, nsplit), dim3(128), 0, st, (const float*)feat, protoT, partial, P, CH,
+                       CH / nsplit, hw, bps, per_sample ? (int64_t)CH * 64 : 0);
+  else
+    hipLaunchKernelGGL(proto_dist_kernel<unsigned short>, dim3(B * bps, nsplit), dim3(128), 0, st, (const unsigned short*)feat, protoT,
+                       partial, P, CH, CH / nsplit, hw, bps, per_sample ? (int64_t)CH * 64 : 0);
   hipLaunchKernelGGL(proto_fuse_kernel, dim3(cdiv(P, PFU_PX)), dim3(256), 0, st, (const float*)partial, logits, inst_flag, run_flag, out,
                      P, C, hw, nsplit, tau, pl, pl1, fl, fl1, per_sample ? C : 0);
   DIGA_CHECK_LAUNCH("diga_proto_classify_fuse");

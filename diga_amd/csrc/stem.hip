@@ -17,8 +17,9 @@ constexpr int PW = 134;        // patch row pitch (133 used)
 // A thread owns output column `lane` of the strip's ROWS rows x 16 channels (64 accumulators): every weight vector
 // read from LDS (4 x b128, broadcast) feeds ROWS x 16 FMAs, every input value 16.  The accumulation order per output
 // is (c, kh, kw), the order of the reference's 147-deep dot product layout [c][kh][kw].
+template <bool OUT_F32>   // OUT_F32: the verification mode keeps the raw output in fp32 (same arithmetic, no bf16 rounding)
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
-                                                   unsigned short* __restrict__ out, float* __restrict__ slab,
+                                                   void* __restrict__ out_v, float* __restrict__ slab,
                                                    const float* __restrict__ shift, int H, int W, int Ho, int Wo,
                                                    int tiles_w, int tiles_h) {
   __shared__ __attribute__((aligned(16))) float sw[147 * 64];   // [k][cout]
@@ -82,15 +83,22 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
   for (int r = 0; r < ROWS; ++r) {
     const int oh = oh0 + r;
     if (oh < Ho && ow < Wo) {
-      u32x4 lo, hi;
+      const size_t e0 = (((size_t)n * Ho + oh) * Wo + ow) * 64 + cg * 16;
+      if constexpr (OUT_F32) {
+        f32x4* o = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out_v) + e0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        lo[i] = pack_bf16x2(acc[r][2 * i], acc[r][2 * i + 1]);
-        hi[i] = pack_bf16x2(acc[r][8 + 2 * i], acc[r][8 + 2 * i + 1]);
+        for (int i = 0; i < 4; ++i) o[i] = f32x4{acc[r][4 * i], acc[r][4 * i + 1], acc[r][4 * i + 2], acc[r][4 * i + 3]};
+      } else {
+        u32x4 lo, hi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          lo[i] = pack_bf16x2(acc[r][2 * i], acc[r][2 * i + 1]);
+          hi[i] = pack_bf16x2(acc[r][8 + 2 * i], acc[r][8 + 2 * i + 1]);
+        }
+        u32x4* o = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(out_v) + e0);
+        o[0] = lo;
+        o[1] = hi;
       }
-      u32x4* o = reinterpret_cast<u32x4*>(out + (((size_t)n * Ho + oh) * Wo + ow) * 64 + cg * 16);
-      o[0] = lo;
-      o[1] = hi;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const float d = acc[r][i] - kshift[i];
@@ -125,16 +133,32 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 
 }  // namespace
 
-extern "C" int diga_stem_conv7x7s2(const float* x, const float* wgt, void* out, float* stat_slab, const float* stat_shift,
-                                   int B, int H, int W, void* stream) {
+namespace {
+int stem_launch(const float* x, const float* wgt, void* out, float* stat_slab, const float* stat_shift, int B, int H, int W,
+                bool out_f32, void* stream) {
   DIGA_CHECK_ARG(B > 0 && H >= 7 && W >= 7, "diga_stem_conv7x7s2: bad dims %dx%dx%d", B, H, W);
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   const int tiles_w = cdiv(Wo, 64), tiles_h = cdiv(Ho, ROWS);
   const int ntiles = B * tiles_h * tiles_w;
   if (x == nullptr) return ntiles;
   DIGA_CHECK_ARG(wgt && out && stat_slab && stat_shift, "diga_stem_conv7x7s2: NULL pointer");
-  hipLaunchKernelGGL(stem_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, x, wgt, (unsigned short*)out, stat_slab,
-                     stat_shift, H, W, Ho, Wo, tiles_w, tiles_h);
+  if (out_f32)
+    hipLaunchKernelGGL(stem_kernel<true>, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, x, wgt, out, stat_slab, stat_shift, H, W, Ho,
+                       Wo, tiles_w, tiles_h);
+  else
+    hipLaunchKernelGGL(stem_kernel<false>, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, x, wgt, out, stat_slab, stat_shift, H, W, Ho,
+                       Wo, tiles_w, tiles_h);
   DIGA_CHECK_LAUNCH("diga_stem_conv7x7s2");
   return DIGA_OK;
+}
+}  // namespace
+
+extern "C" int diga_stem_conv7x7s2(const float* x, const float* wgt, void* out, float* stat_slab, const float* stat_shift,
+                                   int B, int H, int W, void* stream) {
+  return stem_launch(x, wgt, out, stat_slab, stat_shift, B, H, W, false, stream);
+}
+
+extern "C" int diga_stem_conv7x7s2_f32(const float* x, const float* wgt, float* out, float* stat_slab, const float* stat_shift,
+                                       int B, int H, int W, void* stream) {
+  return stem_launch(x, wgt, out, stat_slab, stat_shift, B, H, W, true, stream);
 }

@@ -60,8 +60,9 @@ def pack_conv_weight(w: torch.Tensor, cout_pad: int | None = None) -> torch.Tens
     return pack_taps([w], cout_pad)
 
 
-def pack_taps(ws, cout_pad: int | None = None) -> torch.Tensor:
-    """Several [Cout,Cin,kh,kw] kernels over the same input concatenated along the tap axis (the fused head)."""
+def pack_taps(ws, cout_pad: int | None = None, dtype=torch.bfloat16) -> torch.Tensor:
+    """Several [Cout,Cin,kh,kw] kernels over the same input concatenated along the tap axis (the fused head).
+    dtype=torch.float32 keeps the packed values unrounded (the verification mode splits them into operand planes)."""
     co, ci = ws[0].shape[:2]
     assert ci % 64 == 0 or ci < 64, ci
     cw = min(ci, 64)
@@ -69,7 +70,7 @@ def pack_taps(ws, cout_pad: int | None = None) -> torch.Tensor:
     out = taps.permute(0, 2, 1, 3).reshape(co, -1)
     if cout_pad is not None and cout_pad > co:
         out = torch.cat([out, out.new_zeros(cout_pad - co, out.shape[1])], 0)
-    return out.to(torch.bfloat16).contiguous()
+    return out.to(dtype).contiguous()
 
 
 @dataclass
@@ -81,6 +82,7 @@ class BNP:
     bias: torch.Tensor
     C: int
     off: int = 0        # offset of this layer's scale/shift in the shared buffers
+    lam: float | None = None   # this layer's own lambda_ (ttda:335-336: every module mixes with ITS parameter); None -> Engine.lam
 
 
 class NetWeights:
@@ -103,6 +105,8 @@ class NetWeights:
             nonlocal off
             b = BNP(dev(sd[name + ".running_mean"]), dev(sd[name + ".running_var"]), dev(sd[name + ".weight"]),
                     dev(sd[name + ".bias"]), int(sd[name + ".weight"].shape[0]), off)
+            if name + ".lambda_" in sd:        # SIFABatchNorm2dTrainable's parameter (ttda:369), fp32 as the reference holds it
+                b.lam = float(np.float32(float(sd[name + ".lambda_"])))
             off += b.C
             self.bn[name] = b
 
@@ -141,7 +145,7 @@ class Engine:
 
     def __init__(self, weights: NetWeights, B: int, H: int, W: int, bn_lambda: float = 0.8, group=None,
                  confidence_threshold: float = 0.9, stream: bool = False, conv_tile: int = 0,
-                 autotune: bool = False, fuse_conv3: bool = False, force_exchange: bool = False):
+                 autotune: bool = False, fuse_conv3: bool = False, force_exchange: bool = False, fold_finalize: bool = False):
         """stream=False: x is ONE batch of B samples -> the reference's batch semantics (half_first DAM statistics over
         the batch, prototypes pooled over the batch).  stream=True: x holds B CONSECUTIVE batch-1 frames of a stream
         ("frames in flight"): the trunk runs once over all of them with per-sample DAM statistics (DAM carries no
@@ -178,6 +182,14 @@ class Engine:
         # the statistics / prototype exchange runs whenever there is more than one rank; force_exchange takes the same
         # code path with a single-rank group (how the RCCL calls are exercised on a one-GPU box, tests/test_gpu_dist.py)
         self.exchange = self.world > 1 or (bool(force_exchange) and group is not None)
+        # fold_finalize: where every sample is normalised with its own statistics (batch 1, or a stream's frames in flight) the
+        # DAM finalize can run inside the conv launch (diga_conv_igemm_bf16_dam: the last tile of each (sample, N tile) group
+        # reduces the slab) -- bit-identical scale / shift, 103 launches fewer per pass.  Measured (same-box A/B):
+        # 708 vs 715 frames/s at 2 x 15 frames in flight and 4.09 vs 3.30 ms at one frame per step -- the last tile's reduction
+        # reads the slab with L2-bypassing loads (the XCDs' L2s are not coherent inside a launch) and that serial tail costs more
+        # than the launch it saves -- so it is OFF by default.  Batches (half_first spans samples) and the sharded path (the
+        # sums are exchanged first) always use the separate diga_bn_finalize / reduce + finalize_sums launches.
+        self.fold_finalize = bool(fold_finalize) and not self.exchange and (self.stream or B == 1)
         (self.h1, self.w1), (self.h2, self.w2), (self.h3, self.w3) = feature_grid(H, W)
         self.h, self.wd = self.h3, self.w3
         self.hw = self.h * self.wd
@@ -209,6 +221,7 @@ class Engine:
             return B * ((rows + 31) // 32)
         self.slab = buf(max(self.stem_units * 2 * 64, units(self.h2 * self.w2) * 2 * 256, units(self.h3 * self.w3) * 2 * 2048), f32)
         self.sums = buf(4 * 2048 * self.na, torch.float64)
+        self.ticket = torch.zeros(B * 64, dtype=torch.int32, device=dev)      # (sample, N tile) counters of the fused finalize
         # head / SAM
         self.head_part = buf(self.P * weights.head_cpad, f32)        # z of the head GEMM
         self.head_dy = (C.c_int16 * 18)(*[(t % 9 // 3 - 1) * HEAD_DILS[t // 9] for t in range(18)])
@@ -263,9 +276,10 @@ class Engine:
     def _finalize(self, bn: BNP, ups, rows_per_sample):
         """slab (this rank's B samples x ups units) -> scale/shift of one BN layer."""
         sc, sh = self._affine(bn)
+        lam = self.lam if bn.lam is None else bn.lam
         if self.stream and not self.exchange:
             call("diga_bn_finalize", _p(self.slab), ups, self.B, self.B, 1, bn.C, float(rows_per_sample), 0.0,
-                 _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
+                 _p(bn.running_mean), _p(bn.running_var), _p(bn.weight), _p(bn.bias), lam, 1e-5, _p(sc), _p(sh), _stream())
             return sc, sh
         if self.stream:      # B global batches in flight, one frame of each on this rank: one exchange for all of them
             _, n_a, n_b = group_plan(self.rank, self.world, 1, rows_per_sample)
@@ -273,7 +287,7 @@ class Engine:
             call("diga_bn_reduce_slab", _p(self.slab), ups, self.B, 1 if self.rank == 0 else 0, 1, bn.C, _p(sums), _stream())
             self._all_reduce(sums)
             call("diga_bn_finalize_sums", _p(sums), self.B, bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var), _p(bn.weight),
-                 _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
+                 _p(bn.bias), lam, 1e-5, _p(sc), _p(sh), _stream())
             return sc, sh
         split, n_a, n_b = self._groups(rows_per_sample)
         a_samples = split // rows_per_sample
@@ -282,19 +296,28 @@ class Engine:
             call("diga_bn_reduce_slab", _p(self.slab), ups, self.B, a_samples, 0, bn.C, _p(sums), _stream())
             self._all_reduce(sums)
             call("diga_bn_finalize_sums", _p(sums), 1, bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var), _p(bn.weight),
-                 _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
+                 _p(bn.bias), lam, 1e-5, _p(sc), _p(sh), _stream())
             return sc, sh
         call("diga_bn_finalize", _p(self.slab), ups, self.B, a_samples, 0, bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var),
-             _p(bn.weight), _p(bn.bias), self.lam, 1e-5, _p(sc), _p(sh), _stream())
+             _p(bn.weight), _p(bn.bias), lam, 1e-5, _p(sc), _p(sh), _stream())
         return sc, sh
 
     def _apply(self, raw, sc, sh, res, rsc, rsh, out, M, Cc):
         call("diga_bn_apply", _p(raw), _p(sc), _p(sh), _p(res), _p(rsc), _p(rsh), _p(out), M, Cc, 1,
              self.B if self.stream else 0, _stream())
 
-    def _conv(self, name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn: BNP | None, apply=None):
+    def _conv_bn(self, name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn: BNP):
+        """One trunk conv + its DAM finalize -> (scale, shift) of the BN layer that follows it."""
+        if self.fold_finalize:
+            self._conv(name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn, fold=True)
+            return self._affine(bn)
+        nt = self._conv(name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn)
+        return self._finalize(bn, nt, Ho * Wo)
+
+    def _conv(self, name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn: BNP | None, apply=None, fold=False):
         """One trunk conv.  out=None: statistics only.  apply=(scale, shift, residual): pass 2 of a fused conv3
-        (diga_conv_igemm_bf16_apply; no statistics).  Returns the statistics units per sample."""
+        (diga_conv_igemm_bf16_apply; no statistics).  fold: the DAM finalize runs inside the launch (per-sample statistics).
+        Returns the statistics units per sample."""
         d = ConvDesc()
         d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = self.B, Hin, Win, Cin, Ho, Wo, Cout
         d.stride = stride
@@ -307,7 +330,15 @@ class Engine:
         d.cout_pad = Cout
         d.splitk, d.out_f32, d.tile = 1, 0, self.conv_tile
         wgt = self.w.conv[name]
-        if apply is None:
+        if apply is None and fold:
+            sc, sh = self._affine(bn)
+            lam = self.lam if bn.lam is None else bn.lam
+
+            def launch():
+                call("diga_conv_igemm_bf16_dam", C.byref(d), _p(x), _p(wgt), _p(out), _p(self.slab), _p(bn.running_mean),
+                     _p(bn.running_var), _p(bn.weight), _p(bn.bias), lam, 1e-5, _p(sc), _p(sh), _p(self.ticket), _stream())
+            mode = "stats+fin" if out is None else "conv+fin"
+        elif apply is None:
             def launch():
                 call("diga_conv_igemm_bf16", C.byref(d), _p(x), _p(wgt), _p(out), _p(self.slab), _p(bn.running_mean), _stream())
             mode = "stats" if out is None else "conv"
@@ -401,33 +432,28 @@ class Engine:
                 rows = Ho * Wo
                 # conv1 (1x1, carries the stride) -> bn1 -> relu
                 bn1 = w.bn[pre + ".bn1"]
-                nt = self._conv(pre + ".conv1", cur, self.raw1, Hc, Wc, Cc, Ho, Wo, pl, s, 1, False, bn1)
+                sc, sh = self._conv_bn(pre + ".conv1", cur, self.raw1, Hc, Wc, Cc, Ho, Wo, pl, s, 1, False, bn1)
                 self._tap(pre + ".conv1", self.raw1, (B, Ho, Wo, pl))
-                sc, sh = self._finalize(bn1, nt, rows)
                 self._apply(self.raw1, sc, sh, None, None, None, self.act1, M, pl)
                 self._tap(pre + ".act1", self.act1, (B, Ho, Wo, pl))
                 # conv2 (3x3 dilated, pad = dilation) -> bn2 -> relu
                 bn2 = w.bn[pre + ".bn2"]
-                nt = self._conv(pre + ".conv2", self.act1, self.raw2, Ho, Wo, pl, Ho, Wo, pl, 1, dil, True, bn2)
+                sc, sh = self._conv_bn(pre + ".conv2", self.act1, self.raw2, Ho, Wo, pl, Ho, Wo, pl, 1, dil, True, bn2)
                 self._tap(pre + ".conv2", self.raw2, (B, Ho, Wo, pl))
-                sc, sh = self._finalize(bn2, nt, rows)
                 self._apply(self.raw2, sc, sh, None, None, None, self.act2, M, pl)
                 self._tap(pre + ".act2", self.act2, (B, Ho, Wo, pl))
                 # conv3 (1x1) -> bn3 (+ residual, relu)
                 bn3 = w.bn[pre + ".bn3"]
                 if self.fuse_conv3 and b != 0:
-                    nt = self._conv(pre + ".conv3", self.act2, None, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)      # statistics
-                    sc3, sh3 = self._finalize(bn3, nt, rows)
+                    sc3, sh3 = self._conv_bn(pre + ".conv3", self.act2, None, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)      # statistics
                     self._conv(pre + ".conv3", self.act2, nxt, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, None, apply=(sc3, sh3, cur))
                 else:
-                    nt = self._conv(pre + ".conv3", self.act2, self.raw3, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)
+                    sc3, sh3 = self._conv_bn(pre + ".conv3", self.act2, self.raw3, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)
                     self._tap(pre + ".conv3", self.raw3, (B, Ho, Wo, pl * 4))
-                    sc3, sh3 = self._finalize(bn3, nt, rows)
                     if b == 0:    # downsample branch: 1x1 (stride) + bn on the block input
                         bnd = w.bn[pre + ".downsample.1"]
-                        nt = self._conv(pre + ".downsample.0", cur, self.rawd, Hc, Wc, Cc, Ho, Wo, pl * 4, s, 1, False, bnd)
+                        scd, shd = self._conv_bn(pre + ".downsample.0", cur, self.rawd, Hc, Wc, Cc, Ho, Wo, pl * 4, s, 1, False, bnd)
                         self._tap(pre + ".downsample.0", self.rawd, (B, Ho, Wo, pl * 4))
-                        scd, shd = self._finalize(bnd, nt, rows)
                         self._apply(self.raw3, sc3, sh3, self.rawd, scd, shd, nxt, M, pl * 4)
                     else:
                         self._apply(self.raw3, sc3, sh3, cur, None, None, nxt, M, pl * 4)

@@ -25,6 +25,16 @@ from .engine import FEAT_CH, Engine, NetWeights, _p, _stream
 logger = logging.getLogger("diga_amd")
 affine_par = True
 
+# The reference's DIGA is a pytorch_lightning.LightningModule handed to trainer.test (ttda:1562, train_task.py:73).  Lightning is
+# not a dependency of the kernels: when it is importable DIGA subclasses LightningModule (so a Trainer accepts it), otherwise
+# it is a plain nn.Module with the same hooks, driven by src/eval.py's loop.
+try:
+    import pytorch_lightning as _pl
+    _ModuleBase = _pl.LightningModule
+except ImportError:
+    _pl = None
+    _ModuleBase = nn.Module
+
 
 class AttrDict(dict):
     """dict with attribute access: the reference reads hparams both ways (ttda:1573 vs ttda:1640)."""
@@ -243,6 +253,7 @@ class DeepLabv2AdaptSeg(ResNetMulti):
         self._threshold = 0.9
         self._group = None
         self._sam_state = None
+        self._precision = "bf16"      # "fp32x2" / "fp32x3": the fp32-exact verification mode (diga_amd/verify.py)
         if restore_from is not None:
             self.restore_from = restore_from
             self.restore()
@@ -329,12 +340,24 @@ class DeepLabv2AdaptSeg(ResNetMulti):
         """Plan + buffers for one input shape.  stream=True: the B samples are B consecutive batch-1 frames of a stream
         (per-sample DAM statistics, SAM frame by frame) instead of one batch of B."""
         dev = torch.device("cuda", torch.cuda.current_device())
+        exact = self._precision != "bf16"
+        if exact and (stream or self._group is not None):
+            raise _lib.DigaError("the fp32 verification mode runs single-process batches only (no frames in flight, no process group)")
         if self._weights is None:
-            self._weights = NetWeights({k: v for k, v in self.state_dict().items()}, dev, self.num_classes)
+            sd = {k: v for k, v in self.state_dict().items()}
+            if exact:
+                from .verify import ExactWeights
+                self._weights = ExactWeights(sd, dev, self.num_classes, {"fp32x2": 2, "fp32x3": 3}[self._precision])
+            else:
+                self._weights = NetWeights(sd, dev, self.num_classes)
         key = (B, H, W, bool(stream))
         if key not in self._engines:
-            e = Engine(self._weights, B, H, W, bn_lambda=self._bn_lambda, group=None if stream else self._group,
-                       confidence_threshold=self._threshold, stream=stream, autotune=True)
+            if exact:
+                from .verify import ExactEngine
+                e = ExactEngine(self._weights, B, H, W, bn_lambda=self._bn_lambda, confidence_threshold=self._threshold)
+            else:
+                e = Engine(self._weights, B, H, W, bn_lambda=self._bn_lambda, group=None if stream else self._group,
+                           confidence_threshold=self._threshold, stream=stream, autotune=True)
             if self._sam_state is not None:      # all shapes share the one cross-frame state (ttda:1702-1705)
                 e.run_proto, e.run_flag, e.state_flag = self._sam_state
             self._engines[key] = e
@@ -354,19 +377,29 @@ class DeepLabv2AdaptSeg(ResNetMulti):
 # ------------------------------------------------------------------------------------------------
 # DIGA (ttda:1562-1841)
 # ------------------------------------------------------------------------------------------------
-class DIGA(nn.Module):
-    """Backward-free TTA module: DAM (BN statistic mixing) + SAM (prototype classifier) + fusion."""
+class DIGA(_ModuleBase):
+    """Backward-free TTA module: DAM (BN statistic mixing) + SAM (prototype classifier) + fusion.
+    A pytorch_lightning.LightningModule when Lightning is importable (ttda:1562), else an nn.Module with the same hooks."""
 
-    def __init__(self, net, dataset_info: dict = {}, cfg: object = None, process_group=None):
+    def __init__(self, net, dataset_info: dict = {}, cfg: object = None, process_group=None, precision: str = "bf16"):
+        """precision: "bf16" (the product path) or "fp32x2" / "fp32x3" -- the fp32-exact verification mode: the same kernels
+        with split bf16 operand planes and fp32 activation storage (diga_amd/verify.py), for end-to-end parity runs."""
         super().__init__()
-        self.hparams = AttrDict(dataset_info=_attr(dataset_info), cfg=_attr(cfg))
+        if precision not in ("bf16", "fp32x2", "fp32x3"):
+            raise ValueError(f"precision {precision!r}: expected 'bf16', 'fp32x2' or 'fp32x3'")
+        if _pl is not None:
+            self.save_hyperparameters(logger=False)           # ttda:1569: hparams.net / dataset_info / cfg as the reference keeps them
+            for k in ("dataset_info", "cfg"):                 # item AND attribute access on both (ttda:1573 vs ttda:1640)
+                self.hparams[k] = _attr(self.hparams[k])
+        else:
+            self.hparams = AttrDict(net=net, dataset_info=_attr(dataset_info), cfg=_attr(cfg))
+            self.loggers = []
         self.net = net(num_classes=self.hparams.dataset_info["num_classes"],
                        output_size=self.hparams.dataset_info["image_size"])
         self.test_acc = nn.ModuleList([SegmentationMetric(num_classes=self.hparams.dataset_info["num_classes"], ignore_index=255)
                                        for _ in self.hparams.dataset_info["test_list"]])
         self.test_step_global = 0
         self.logged = {}
-        self.loggers = []
         self._replace_bn()
         self._configure_bn_running_stats()
         Cn = self.hparams.dataset_info["num_classes"]
@@ -379,10 +412,16 @@ class DIGA(nn.Module):
         self.net._bn_lambda = float(self.hparams.cfg.bn_lambda)
         self.net._threshold = float(self.hparams.cfg.confidence_threshold)
         self.net._group = process_group
+        self.net._precision = precision
 
     # ---- cross-frame state with the reference's lazy-attribute semantics (ttda:1702-1705)
-    @property
-    def device(self):
+    if _pl is None:
+        @property
+        def device(self):          # LightningModule's own property otherwise (the Trainer moves the module)
+            return torch.device("cuda", torch.cuda.current_device())
+
+    def _cuda(self):
+        """The device every kernel call runs on: the current HIP device (there is no CPU path)."""
         return torch.device("cuda", torch.cuda.current_device())
 
     def __getattr__(self, name):
@@ -403,9 +442,15 @@ class DIGA(nn.Module):
 
     def log(self, name, value, **kw):
         self.logged[name] = float(value) if torch.is_tensor(value) and value.numel() == 1 else value
+        if _pl is not None and getattr(self, "_trainer", None) is not None:      # inside trainer.test: Lightning's own logging too
+            super().log(name, value, **kw)
 
     def on_test_start(self):
         pass
+
+    def on_test_epoch_end(self):
+        """Lightning >= 2.0 spelling of the epoch-end hook (test_epoch_end(outputs) is the 1.x one the reference uses, ttda:1647)."""
+        return self.test_epoch_end(None)
 
     # ---- reference API
     def forward(self, x: torch.Tensor):
@@ -455,7 +500,7 @@ class DIGA(nn.Module):
         xs, ys = [b[0] for b in batches], [b[1] for b in batches]
         if any(int(x.shape[0]) != 1 for x in xs):
             raise ValueError("test_step_stream pipelines batch-1 frames; use test_step for real batches")
-        x = torch.cat([t.to(self.device, torch.float32) for t in xs]).contiguous()
+        x = torch.cat([t.to(self._cuda(), torch.float32) for t in xs]).contiguous()
         y = torch.cat([self._labels_on_device(t) for t in ys]).contiguous()
         eng = self.net.engine(int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), stream=True)
         self._last_engine = eng
@@ -469,7 +514,7 @@ class DIGA(nn.Module):
         return probs
 
     def _labels_on_device(self, y):
-        y = y.to(self.device)
+        y = y.to(self._cuda())
         if y.dtype not in (torch.int32, torch.int64):
             y = y.long()
         return y.contiguous()
@@ -478,7 +523,7 @@ class DIGA(nn.Module):
         """ttda:1623-1645.  Returns (probs [B,C,h,w], {}); probs on the CPU as the reference does unless
         to_cpu=False."""
         x, y = pair
-        x = x.to(self.device, torch.float32).contiguous()
+        x = x.to(self._cuda(), torch.float32).contiguous()
         eng = self.net.engine(int(x.shape[0]), int(x.shape[2]), int(x.shape[3]))
         self._last_engine = eng
         probs = eng.forward_and_adapt(x, self._labels_on_device(y), self.hparams.cfg)
@@ -498,19 +543,29 @@ class DIGA(nn.Module):
             m.reset()
         return res
 
-    # ---- SAM helpers with the reference's signatures, each one a kernel call (NCHW fp32 tensors in/out)
+    # ---- SAM helpers with the reference's signatures, each one a kernel call (NCHW fp32 tensors in/out).
+    # The caller's features are arbitrary fp32 values and the reference computes these functions in fp32 (ttda:1712-1805), so
+    # the helpers run the fp32-feature kernels (diga_proto_pool_f32 / diga_proto_classify_fuse_f32): nothing is rounded to bf16.
     def _feat_nhwc(self, feature):
-        feature = feature.to(self.device, torch.float32).contiguous()
+        """NCHW fp32 -> NHWC fp32 [P][CH] on the device."""
+        feature = feature.to(self._cuda(), torch.float32).contiguous()
         B, CH, h, w = feature.shape
-        out = torch.empty(B * h * w * CH, dtype=torch.bfloat16, device=self.device)
+        out = torch.empty(B * h * w * CH, dtype=torch.float32, device=self._cuda())
+        call("diga_nchw_f32_to_nhwc_f32", _p(feature), _p(out), B, h * w, CH, _stream())
+        return out
+
+    def _feat_nhwc_bf16(self, feature):
+        feature = feature.to(self._cuda(), torch.float32).contiguous()
+        B, CH, h, w = feature.shape
+        out = torch.empty(B * h * w * CH, dtype=torch.bfloat16, device=self._cuda())
         call("diga_nchw_f32_to_nhwc_bf16", _p(feature), _p(out), B, h * w, CH, _stream())
         return out
 
     def high_confident_proto_label(self, outputs, threshold):
         """ttda:1662-1676.  outputs: logits [B,C,H,W] -> int64 [B,H,W] in {0..C-1, 255}."""
-        lg = outputs.to(self.device, torch.float32).contiguous()
+        lg = outputs.to(self._cuda(), torch.float32).contiguous()
         B, Cn, h, w = lg.shape
-        lab = torch.empty(B * h * w, dtype=torch.int32, device=self.device)
+        lab = torch.empty(B * h * w, dtype=torch.int32, device=self._cuda())
         call("diga_head_finish_pseudo_label", None, 1, Cn, None, _p(lg), None, _p(lab), B, Cn, h * w, _f32(threshold), 0, _stream())
         return lab.reshape(B, h, w).long()
 
@@ -519,20 +574,20 @@ class DIGA(nn.Module):
         Cn = self.hparams.dataset_info["num_classes"]
         B, CH, h, w = feature.shape
         f = self._feat_nhwc(feature)
-        labs = y.to(self.device).reshape(-1).to(torch.int32).contiguous()
+        labs = y.to(self._cuda()).reshape(-1).to(torch.int32).contiguous()
         Pn = B * h * w
-        work = torch.empty(call("diga_proto_pool_work_bytes", 1, Pn, Cn, CH), dtype=torch.uint8, device=self.device)
-        sums = torch.empty(Cn * CH, dtype=torch.float32, device=self.device)
-        counts = torch.empty(Cn, dtype=torch.int32, device=self.device)
-        call("diga_proto_pool", _p(f), _p(labs), 1, Pn, Cn, CH, _p(work), _p(sums), _p(counts), _stream())
+        work = torch.empty(call("diga_proto_pool_work_bytes", 1, Pn, Cn, CH), dtype=torch.uint8, device=self._cuda())
+        sums = torch.empty(Cn * CH, dtype=torch.float32, device=self._cuda())
+        counts = torch.empty(Cn, dtype=torch.int32, device=self._cuda())
+        call("diga_proto_pool_f32", _p(f), _p(labs), 1, Pn, Cn, CH, _p(work), _p(sums), _p(counts), _stream())
         # mean = sum / n via the update kernel (state_flag = 0 -> running := instance)
-        inst = torch.empty(Cn, CH, dtype=torch.float32, device=self.device)
-        iflag = torch.empty(Cn, dtype=torch.float32, device=self.device)
+        inst = torch.empty(Cn, CH, dtype=torch.float32, device=self._cuda())
+        iflag = torch.empty(Cn, dtype=torch.float32, device=self._cuda())
         run, rflag = torch.zeros_like(inst), torch.zeros_like(iflag)
         cnt2 = torch.cat([counts, torch.zeros_like(counts)])
         sums2 = torch.cat([sums, torch.zeros_like(sums)])
         call("diga_proto_update", _p(sums2), _p(cnt2), Cn, CH, _p(inst), _p(iflag), _p(run), _p(rflag),
-             _p(torch.zeros(1, dtype=torch.int32, device=self.device)), 1.0, 0.0, _stream())
+             _p(torch.zeros(1, dtype=torch.int32, device=self._cuda())), 1.0, 0.0, _stream())
         return inst, iflag
 
     # ---- optional extension, NOT part of the reference's DIGA and not called by forward_and_adapt
@@ -541,30 +596,32 @@ class DIGA(nn.Module):
         high_confident_proto_label) -> (inst int64 [B,h,w]: 0 = background / ignore, else the component's number inside
         its class, from 1 in raster order; ncomp int64 [B,C])."""
         from . import instances
-        inst, ncomp = instances.ccl_label(y.to(self.device), self.hparams.dataset_info["num_classes"], connectivity)
+        inst, ncomp = instances.ccl_label(y.to(self._cuda()), self.hparams.dataset_info["num_classes"], connectivity)
         return inst.long(), ncomp.long()
 
     def cal_instance_proto(self, feature, y, connectivity: int = 8, max_instances: int = 4096):
         """cal_proto per connected component instead of per class: feature [B,CH,h,w], y [B,h,w] ->
-        instances.InstanceTable (protos [N,CH], counts, classes, samples, total), rows in (sample, class, number) order."""
+        instances.InstanceTable (protos [N,CH], counts, classes, samples, total), rows in (sample, class, number) order.
+        Unlike the reference-mirroring helpers this optional extension pools the features as the network stores them, in
+        bf16: fp32 input is rounded to bf16 first (exact for features that came out of net(x, feat=True))."""
         from . import instances
         Cn = self.hparams.dataset_info["num_classes"]
         B, CH, h, w = feature.shape
-        labs = y.to(self.device).reshape(B, h, w)
+        labs = y.to(self._cuda()).reshape(B, h, w)
         inst, ncomp = instances.ccl_label(labs, Cn, connectivity)
-        return instances.instance_prototypes(self._feat_nhwc(feature).reshape(B * h * w, CH), labs, inst, ncomp, Cn, max_instances)
+        return instances.instance_prototypes(self._feat_nhwc_bf16(feature).reshape(B * h * w, CH), labs, inst, ncomp, Cn, max_instances)
 
     def cal_pred_of_proto(self, feature, proto, exists_flag, tau=1.0):
         """ttda:1712-1734 -> weight [B,C,H,W] (NaN where no class exists / all underflow)."""
         B, CH, h, w = feature.shape
         Cn = proto.shape[0]
         f = self._feat_nhwc(feature)
-        pr = proto.to(self.device, torch.float32).contiguous()
-        fl = exists_flag.to(self.device, torch.float32).contiguous()
-        zeros = torch.zeros(B, Cn, h, w, dtype=torch.float32, device=self.device)
+        pr = proto.to(self._cuda(), torch.float32).contiguous()
+        fl = exists_flag.to(self._cuda(), torch.float32).contiguous()
+        zeros = torch.zeros(B, Cn, h, w, dtype=torch.float32, device=self._cuda())
         out = torch.empty_like(zeros)
-        work = torch.empty(call("diga_proto_classify_work_bytes", B * h * w, CH), dtype=torch.uint8, device=self.device)
-        call("diga_proto_classify_fuse", _p(f), _p(zeros), _p(pr), _p(fl), _p(pr), _p(fl), _p(out), _p(work), B, Cn, h * w, CH,
+        work = torch.empty(call("diga_proto_classify_work_bytes", B * h * w, CH), dtype=torch.uint8, device=self._cuda())
+        call("diga_proto_classify_fuse_f32", _p(f), _p(zeros), _p(pr), _p(fl), _p(pr), _p(fl), _p(out), _p(work), B, Cn, h * w, CH,
              float(tau), 1.0, 0.0, 1.0, 0.0, _stream())
         return out
 
@@ -574,19 +631,19 @@ class DIGA(nn.Module):
         B, CH, h, w = feature.shape
         f = self._feat_nhwc(feature)
         Pn = B * h * w
-        labs = torch.cat([torch.full((Pn,), 255, dtype=torch.int32, device=self.device),
-                          y.to(self.device).reshape(-1).to(torch.int32)]).contiguous()
-        work = torch.empty(call("diga_proto_pool_work_bytes", 2, Pn, Cn, CH), dtype=torch.uint8, device=self.device)
-        sums = torch.empty(2 * Cn * CH, dtype=torch.float32, device=self.device)
-        counts = torch.empty(2 * Cn, dtype=torch.int32, device=self.device)
-        call("diga_proto_pool", _p(f), _p(labs), 2, Pn, Cn, CH, _p(work), _p(sums), _p(counts), _stream())
-        run = classifier_proto.to(self.device, torch.float32).clone().contiguous()
-        rflag = classifier_proto_exists_flag.to(self.device, torch.float32).clone().contiguous()
-        inst = torch.empty(Cn, CH, dtype=torch.float32, device=self.device)
-        iflag = torch.empty(Cn, dtype=torch.float32, device=self.device)
+        labs = torch.cat([torch.full((Pn,), 255, dtype=torch.int32, device=self._cuda()),
+                          y.to(self._cuda()).reshape(-1).to(torch.int32)]).contiguous()
+        work = torch.empty(call("diga_proto_pool_work_bytes", 2, Pn, Cn, CH), dtype=torch.uint8, device=self._cuda())
+        sums = torch.empty(2 * Cn * CH, dtype=torch.float32, device=self._cuda())
+        counts = torch.empty(2 * Cn, dtype=torch.int32, device=self._cuda())
+        call("diga_proto_pool_f32", _p(f), _p(labs), 2, Pn, Cn, CH, _p(work), _p(sums), _p(counts), _stream())
+        run = classifier_proto.to(self._cuda(), torch.float32).clone().contiguous()
+        rflag = classifier_proto_exists_flag.to(self._cuda(), torch.float32).clone().contiguous()
+        inst = torch.empty(Cn, CH, dtype=torch.float32, device=self._cuda())
+        iflag = torch.empty(Cn, dtype=torch.float32, device=self._cuda())
         rho = 0.0 if rho is None else float(rho)
         call("diga_proto_update", _p(sums), _p(counts), Cn, CH, _p(inst), _p(iflag), _p(run), _p(rflag),
-             _p(torch.ones(1, dtype=torch.int32, device=self.device)), _f32(1 - rho), _f32(rho), _stream())
+             _p(torch.ones(1, dtype=torch.int32, device=self._cuda())), _f32(1 - rho), _f32(rho), _stream())
         return run, rflag
 
     def multi_proto_label(self, feature, outputs, y, class_names, cfg):
@@ -594,7 +651,7 @@ class DIGA(nn.Module):
         cfg = _attr(cfg)
         B, CH, h, w = feature.shape
         Cn = outputs.shape[1]
-        dev = self.device
+        dev = self._cuda()
         f = self._feat_nhwc(feature)
         lg = outputs.to(dev, torch.float32).contiguous()
         yd = self._labels_on_device(y)
@@ -607,7 +664,7 @@ class DIGA(nn.Module):
         work = torch.empty(call("diga_proto_pool_work_bytes", 2, Pn, Cn, CH), dtype=torch.uint8, device=dev)
         sums = torch.empty(2 * Cn * CH, dtype=torch.float32, device=dev)
         counts = torch.empty(2 * Cn, dtype=torch.int32, device=dev)
-        call("diga_proto_pool", _p(f), _p(labels), 2, Pn, Cn, CH, _p(work), _p(sums), _p(counts), _stream())
+        call("diga_proto_pool_f32", _p(f), _p(labels), 2, Pn, Cn, CH, _p(work), _p(sums), _p(counts), _stream())
         if self._run_proto.shape[1] != CH:          # helper used with a non-2048 feature width (tests)
             self._run_proto = torch.zeros(Cn, CH, dtype=torch.float32, device=dev)
             self._run_flag.zero_()
@@ -621,7 +678,7 @@ class DIGA(nn.Module):
         out = torch.empty_like(zeros)
         pl = float(cfg.proto_lambda)
         cwork = torch.empty(call("diga_proto_classify_work_bytes", Pn, CH), dtype=torch.uint8, device=dev)
-        call("diga_proto_classify_fuse", _p(f), _p(zeros), _p(inst), _p(iflag), _p(self._run_proto), _p(self._run_flag), _p(out),
+        call("diga_proto_classify_fuse_f32", _p(f), _p(zeros), _p(inst), _p(iflag), _p(self._run_proto), _p(self._run_flag), _p(out),
              _p(cwork), B, Cn, h * w, CH, 1.0, _f32(pl), _f32(1 - pl), 1.0, 0.0, _stream())
         return out, {}
 
@@ -630,6 +687,8 @@ class DIGA(nn.Module):
         for m in self.net.modules():
             if isinstance(m, nn.BatchNorm2d):
                 m.lambda_.data = torch.tensor(self.hparams.cfg.bn_lambda)
+        self.net._bn_lambda = float(self.hparams.cfg.bn_lambda)
+        self.net.invalidate()          # packed per-layer lambdas / cached engines are stale now
 
     def _replace_bn(self):
         for n, module in list(self.net.named_modules()):

@@ -53,20 +53,38 @@ typedef struct {
   int32_t cout_pad;            /* rows of wgt (>= Cout, multiple of the N tile); padding rows are zero */
   int32_t splitk;              /* >= 1; > 1 only with out_f32 */
   int32_t out_f32;             /* 0: out = bf16 [M][Cout];  1: out = fp32 [splitk][M][cout_pad] partials */
-  int32_t tile;                /* 0 = auto; else tile-config id (see diga_conv_tile_info) */
+  int32_t tile;                /* 0 = auto; else tile-config id */
+  int32_t nplanes;             /* 0 / 1: bf16 operands (the product path).  2 / 3: verification mode -- `in` is nplanes bf16
+                                * planes [nplanes][B*H*W][Cin] whose SUM is the fp32 activation (hi = bf16(x), lo = bf16(x - hi),
+                                * ...), `wgt` likewise [nplanes][cout_pad][K]; the plane products (a, b) with a + b < nplanes are
+                                * accumulated into the same fp32 accumulators (3 terms: "bf16x3", ~2^-17 relative; 6 terms:
+                                * "bf16x6", fp32-grade).  Requires out_f32 and splitk == 1. */
 } diga_conv_desc;
 
 /* Number of statistics units diga_conv_igemm_bf16 writes for `desc`: B * ceil(Ho*Wo / 32).  A unit is
  * 32 consecutive output rows of ONE sample (M tiles never straddle samples), independent of the tile shape. */
 int diga_conv_stat_units(const diga_conv_desc* desc);
 
-/* in: bf16 NHWC; wgt: bf16 [cout_pad][Cin/64][ntaps][64] (K order = channel chunk, tap, channel); out: see desc.out_f32;
+/* in: bf16 NHWC; wgt: bf16 [cout_pad][Cin/64][ntaps][64] (K order = channel chunk, tap, channel); out: see desc.out_f32
+ * (with out_f32 and splitk == 1 a stat_slab may be given too: fp32 output + statistics, the verification mode's form);
  * stat_slab: NULL, or fp32 [stat_units][2 (sum, sumsq)][Cout] of *shifted* values (x - stat_shift[c])
  * taken from the fp32 accumulators, sample-major; stat_shift: fp32 [Cout] (the source running_mean:
  * the shifted-data variance algorithm stays accurate when mean >> std).  Which samples form the
  * reference's half_first groups is decided in diga_bn_finalize, not here. */
 int diga_conv_igemm_bf16(const diga_conv_desc* desc, const void* in, const void* wgt, void* out,
                          float* stat_slab, const float* stat_shift, void* stream);
+/* The same convolution with the DAM finalize folded into the launch (SIFABatchNorm2d.forward's statistics and lambda-mix,
+ * ttda:313-343, for the case where EVERY SAMPLE is normalised with its own statistics: batch 1, or the frames of a batch-1
+ * stream in flight): the last tile to finish of each (sample, N tile) group reduces that sample's slab columns in the fixed
+ * order of diga_bn_finalize(per_sample = 1) and writes scale / shift [B][Cout] -- bit-identical to
+ * diga_conv_igemm_bf16 + diga_bn_finalize, one launch less per BN layer.
+ * ticket: uint32 [diga_conv_dam_ticket_words(desc)] device words, ZERO before the first launch; every launch leaves them
+ * zero.  Launches that share a ticket buffer must not overlap (one buffer per stream). */
+int diga_conv_dam_ticket_words(const diga_conv_desc* desc);
+int diga_conv_igemm_bf16_dam(const diga_conv_desc* desc, const void* in, const void* wgt, void* out, float* stat_slab,
+                             const float* running_mean, const float* running_var, const float* weight,
+                             const float* bias, float lam, float eps, float* scale, float* shift,
+                             uint32_t* ticket, void* stream);
 /* out == NULL with a stat_slab: statistics only, nothing is stored.  Together with the entry point below this
  * replaces "conv3 -> bn3 -> += residual -> relu" (adaptseg:93-100) by two passes over the same GEMM: pass 1 takes
  * the DAM statistics, diga_bn_finalize makes the affine, pass 2 recomputes the conv and writes
@@ -299,6 +317,34 @@ int diga_preprocess_image(const void* img, int img_is_u8, float* out, int B, int
  * device; out int64 (out_is_i64) or int32; ids outside the table -> 255 (numpy would raise). */
 int diga_map_labels(const void* ids, int ids_kind, const int32_t* lut, int nlut, void* out, int out_is_i64,
                     int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fp32 forms: (a) the verification mode (fp32-exact end-to-end parity run: the reference is fp32 end to end,
+ * ttda:1634-1645; activations travel as fp32 + bf16 operand planes, see diga_conv_desc.nplanes) and (b) the helper API
+ * called with arbitrary fp32 feature tensors (cal_proto / cal_pred_of_proto, ttda:1712-1805, compute in fp32).
+ * ------------------------------------------------------------------------------------------ */
+/* diga_stem_conv7x7s2 with the raw output kept in fp32 NHWC [B,Ho,Wo,64]. */
+int diga_stem_conv7x7s2_f32(const float* x, const float* wgt, float* out, float* stat_slab,
+                            const float* stat_shift, int B, int H, int W, void* stream);
+/* diga_bn_apply on fp32 data: raw, res fp32 [M][C]; y -> out_f32 (fp32 [M][C], may be NULL) and/or out_planes (bf16
+ * [nplanes][M][C], may be NULL): plane 0 = bf16(y), plane q = bf16(y - planes before it) (adaptseg:86-100). */
+int diga_bn_apply_f32(const float* raw, const float* scale, const float* shift, const float* res,
+                      const float* res_scale, const float* res_shift, float* out_f32, void* out_planes,
+                      int nplanes, int64_t M, int C, int relu, void* stream);
+/* diga_bn_relu_maxpool on fp32 data (adaptseg:179-181), outputs as diga_bn_apply_f32. */
+int diga_bn_relu_maxpool_f32(const float* raw, const float* scale, const float* shift, float* out_f32,
+                             void* out_planes, int nplanes, int B, int H, int W, int C, int Ho, int Wo, void* stream);
+/* x fp32 [n] -> bf16 planes [nplanes][n] whose sum is x (weights / inputs of the verification mode). */
+int diga_split_planes_f32(const float* x, void* planes, int nplanes, int64_t n, void* stream);
+/* diga_proto_pool / diga_proto_classify_fuse with fp32 features [P][CH] (same work sizes, same arithmetic order). */
+int diga_proto_pool_f32(const float* feat, const int32_t* labels, int nsets, int64_t P, int C, int CH,
+                        void* work, float* sums, int32_t* counts, void* stream);
+int diga_proto_classify_fuse_f32(const float* feat, const float* logits, const float* inst_proto,
+                                 const float* inst_flag, const float* run_proto, const float* run_flag,
+                                 float* out, void* work, int B, int C, int hw, int CH, float tau, float pl,
+                                 float pl1, float fl, float fl1, void* stream);
+int diga_nchw_f32_to_nhwc_f32(const float* in, float* out, int B, int HW, int C, void* stream);
+int diga_nhwc_f32_to_nchw_f32(const float* in, float* out, int B, int HW, int C, void* stream);
 
 /* Layout helpers for the Python-visible API (net(x, feat=True) returns NCHW fp32, adaptseg:188). */
 int diga_nhwc_bf16_to_nchw_f32(const void* in, float* out, int B, int HW, int C, void* stream);

@@ -187,6 +187,20 @@ def gen_fn_tail(m):
     np.savez_compressed(os.path.join(GOLD, "fn_tail.npz"), **out)
 
 
+def classifier_mass64(feat, proto, flag):
+    """The normaliser of cal_pred_of_proto (ttda:1729-1733), sum_c exp(-||proto_c - f||) * flag_c, evaluated in float64 from the
+    reference's own features and prototypes.  Where it is below ~1e-33 the reference's fp32 weights are denormals (a few bits)
+    or flushed to 0 (the 0/0 -> NaN branch): its probabilities there are quantisation noise, and the fixtures mark those pixels."""
+    f = feat.double()
+    mass = torch.zeros(f.shape[0], f.shape[2], f.shape[3], dtype=torch.float64)
+    for c in range(proto.shape[0]):
+        if float(flag[c]) == 0:
+            continue
+        d = (f - proto[c].double()[None, :, None, None]).pow(2).sum(1).sqrt()
+        mass += torch.exp(-d)
+    return mass
+
+
 def run_sequence(m, frames, taps_first=None):
     """Run forward_and_adapt + step() tail over a list of (x, y) frames with fresh SAM state."""
     if hasattr(m, "classifier_running_proto"):
@@ -201,9 +215,18 @@ def run_sequence(m, frames, taps_first=None):
             probs, _ = m.forward_and_adapt((x, y))
             up = torch.nn.Upsample(size=y.shape[-2:], mode="bilinear")(probs)
             metric.update(up, y)
+            sm = logits.softmax(1).topk(2, dim=1)[0]
+            top2 = up.topk(2, dim=1)[0]
+            inst_proto, inst_flag = m.cal_proto(feat, pl)
+            lowmass = (classifier_mass64(feat, inst_proto, inst_flag) < 1e-33) | \
+                      (classifier_mass64(feat, m.classifier_running_proto, m.classifier_running_proto_exists_flag) < 1e-33)
         res.append(dict(feat=feat, logits=logits, pseudo=pl, probs=probs, pred=up.argmax(1),
                         run=m.classifier_running_proto.clone(), rflag=m.classifier_running_proto_exists_flag.clone(),
-                        hist=metric.hist.clone()))
+                        hist=metric.hist.clone(),
+                        # how far every integer decision is from flipping: the confidence rule's distance to the bar and the
+                        # top-2 gaps of the pseudo-label soft-max and of the up-sampled fused probabilities
+                        pl_pmax=sm[:, 0].clone(), pl_gap=(sm[:, 0] - sm[:, 1]).clone(), pred_gap=(top2[:, 0] - top2[:, 1]).clone(),
+                        pred_nan=torch.isnan(up).any(1), lowmass=lowmass))
     return res, metric
 
 
@@ -258,6 +281,10 @@ def gen_net_full(m):
         for k in ("logits", "pseudo", "probs", "run", "rflag", "hist"):
             out[f"{t}_{k}"] = np_(r[k])
         out[f"{t}_pred"] = np_(r["pred"]).astype(np.uint8)
+        out[f"{t}_pl_pmax"] = np_(r["pl_pmax"])
+        out[f"{t}_pl_gap_bucket"] = gap_bucket(r["pl_gap"])
+        out[f"{t}_pred_gap_bucket"] = gap_bucket(r["pred_gap"])
+        out[f"{t}_lowmass"] = np_(r["lowmass"])
     out["miou"] = np.array([float(metric.compute()), float(metric.compute_iou("16")), float(metric.compute_iou("13"))])
     np.savez_compressed(os.path.join(GOLD, "net_full.npz"), **out)
 
@@ -286,6 +313,16 @@ def gen_net_multires(m):
 STREAM_FRAMES = 30
 
 
+def gap_bucket(gap):
+    """top-2 gap -> uint8 bucket floor(-log10(gap)) clipped to [0, 9]; NaN gaps (0/0 pixels) -> 255.  A decision whose
+    bucket is b can flip under a perturbation of about 10^-b: the tests state their bit-exactness band in these units."""
+    g = np_(gap).astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        b = np.floor(-np.log10(g))
+    b = np.where(np.isnan(g), 255, np.clip(np.where(np.isinf(b), 9, b), 0, 9))
+    return b.astype(np.uint8)
+
+
 def gen_net_stream(m):
     """BASELINE configs[1] as the bench runs it: one batch-1 stream of 1024x512 frames (frame t = synth_frame(t)), fresh
     prototypes, the reference's forward_and_adapt + Upsample + SegmentationMetric.  Stored per frame: the cumulative
@@ -299,9 +336,114 @@ def gen_net_stream(m):
         out[f"st_{t}_rflag"] = np_(r["rflag"])
         out[f"st_{t}_pred_count"] = np.bincount(np_(r["pred"]).ravel(), minlength=19).astype(np.int64)
         out[f"st_{t}_nan_pixels"] = np.int64(torch.isnan(r["probs"]).any(1).sum())
+        out[f"st_{t}_logits_sub"] = np_(r["logits"][:, :, ::4, ::4])
+        out[f"st_{t}_pseudo"] = np_(r["pseudo"]).astype(np.uint8)
+        out[f"st_{t}_pl_pmax"] = np_(r["pl_pmax"])
+        out[f"st_{t}_pl_gap_bucket"] = gap_bucket(r["pl_gap"])
+        out[f"st_{t}_pred"] = np_(r["pred"]).astype(np.uint8)
+        out[f"st_{t}_pred_gap_bucket"] = gap_bucket(r["pred_gap"])
+        out[f"st_{t}_run_norm"] = np_(r["run"].norm(dim=1))
+        out[f"st_{t}_lowmass"] = np_(r["lowmass"])
+    out["st_run_final"] = np_(res[-1]["run"])
     out["st_miou"] = np.array([float(metric.compute()), float(metric.compute_iou("16")), float(metric.compute_iou("13"))])
     out["st_frames"] = np.int64(STREAM_FRAMES)
     np.savez_compressed(os.path.join(GOLD, "net_stream.npz"), **out)
+
+
+MS_SEEDS = (1, 2, 3, 4)
+MS_FRAMES = 30
+
+
+def gen_net_streams_ms(m):
+    """Four more 30-frame 1024x512 batch-1 streams (frame seeds 1..4, same weights): the reference's mIoU-19/16/13 and
+    final confusion matrix of each.  The bf16 product path is gated on the MEAN deviation over these streams and
+    net_stream.npz (seed 0): one stream's deviation is a single draw of the bf16 rounding noise."""
+    out = {}
+    for sd in MS_SEEDS:
+        frames = [synth.synth_frame(t, 1, 512, 1024, seed=sd) for t in range(MS_FRAMES)]
+        res, metric = run_sequence(m, frames)
+        out[f"ms{sd}_miou"] = np.array([float(metric.compute()), float(metric.compute_iou("16")), float(metric.compute_iou("13"))])
+        out[f"ms{sd}_hist"] = np_(res[-1]["hist"]).astype(np.int64)
+        out[f"ms{sd}_rflag"] = np_(res[-1]["rflag"])
+        out[f"ms{sd}_x0_sha"] = np.array(sha(frames[0][0]))
+        print("stream seed", sd, out[f"ms{sd}_miou"], flush=True)
+    out["ms_seeds"] = np.array(MS_SEEDS)
+    out["ms_frames"] = np.int64(MS_FRAMES)
+    np.savez_compressed(os.path.join(GOLD, "net_streams_ms.npz"), **out)
+
+
+LONG_FRAMES = 102
+
+
+def gen_net_long(m):
+    """BASELINE configs[4] as a LONG stream: 102 batch-1 frames cycling 1280x720 / 1024x512 / 960x540 without resetting
+    the prototypes (ttda:1702-1705): ~100 EMA steps (ttda:1764).  Stored per frame: the running prototypes' norms and
+    flags, the cumulative confusion matrix, NaN-pixel count and the prediction's class histogram; the final prototypes."""
+    out = {}
+    if hasattr(m, "classifier_running_proto"):
+        del m.classifier_running_proto
+    metric = T.SegmentationMetric(num_classes=19, ignore_index=255)
+    for t in range(LONG_FRAMES):
+        H, W = MULTIRES[t % 3]
+        x, y = synth.synth_frame(t, 1, H, W)
+        x, y = torch.from_numpy(x), torch.from_numpy(y)
+        with torch.no_grad():
+            probs, _ = m.forward_and_adapt((x, y))
+            up = torch.nn.Upsample(size=y.shape[-2:], mode="bilinear")(probs)
+            metric.update(up, y)
+        run = m.classifier_running_proto
+        out[f"lg_{t}_run_norm"] = np_(run.norm(dim=1))
+        out[f"lg_{t}_run_sub"] = np_(run[:, ::64])
+        out[f"lg_{t}_rflag"] = np_(m.classifier_running_proto_exists_flag)
+        out[f"lg_{t}_hist"] = np_(metric.hist).astype(np.int64)
+        out[f"lg_{t}_nan_pixels"] = np.int64(torch.isnan(probs).any(1).sum())
+        out[f"lg_{t}_pred_count"] = np.bincount(np_(up.argmax(1)).ravel(), minlength=19).astype(np.int64)
+        if t % 10 == 0:
+            print("long stream frame", t, float(metric.compute()), flush=True)
+    out["lg_run_final"] = np_(m.classifier_running_proto)
+    out["lg_frames"] = np.int64(LONG_FRAMES)
+    out["lg_shapes"] = np.array(MULTIRES)
+    out["lg_miou"] = np.array([float(metric.compute()), float(metric.compute_iou("16")), float(metric.compute_iou("13"))])
+    np.savez_compressed(os.path.join(GOLD, "net_long.npz"), **out)
+
+
+def gen_net_b8(m):
+    """BASELINE configs[2]'s batch: ONE batch of 8 frames (half_first = sample 0 vs samples 1..7, ttda:313-320), the
+    reference run with batch_size 8.  b8s: 65x129 inputs, 3 frames (everything stored); b8f: 1024x512, 2 frames (seed +
+    EMA branch; logits sub-sampled, integers in full)."""
+    out = {}
+    hooks, taps = [], {}
+    for n, mod in m.net.named_modules():
+        if n in ("bn1", "layer1.0.bn1", "layer2.0.downsample.1", "layer3.22.bn3", "layer4.2.bn3"):
+            hooks.append(mod.register_forward_hook(lambda _m, _i, o, n=n: taps.__setitem__(n, o.detach().clone())))
+    for tag, (H, W, nfr) in dict(b8s=(65, 129, 3), b8f=(512, 1024, 2)).items():
+        frames = [synth.synth_frame(200 + t, 8, H, W) for t in range(nfr)]
+        taps.clear()
+        if tag == "b8s":
+            with torch.no_grad():
+                m.net(torch.from_numpy(frames[0][0]), feat=True)
+            for k, v in taps.items():
+                out[f"{tag}_tap_{k}"] = np_(v[:, ::16])
+        res, metric = run_sequence(m, frames)
+        out[f"{tag}_shape"] = np.array([8, H, W])
+        for t, r in enumerate(res):
+            out[f"{tag}_{t}_x_sha"] = np.array(sha(frames[t][0]))
+            small = tag == "b8s"
+            out[f"{tag}_{t}_logits"] = np_(r["logits"] if small else r["logits"][:, :, ::4, ::4])
+            out[f"{tag}_{t}_probs"] = np_(r["probs"] if small else r["probs"][:, :, ::4, ::4])
+            out[f"{tag}_{t}_feat_sub"] = np_(r["feat"][:, ::64] if small else r["feat"][:, ::64, ::4, ::4])
+            for k in ("pseudo", "run", "rflag", "hist"):
+                out[f"{tag}_{t}_{k}"] = np_(r[k])
+            out[f"{tag}_{t}_pred"] = np_(r["pred"]).astype(np.uint8)
+            out[f"{tag}_{t}_pl_pmax"] = np_(r["pl_pmax"])
+            out[f"{tag}_{t}_pl_gap_bucket"] = gap_bucket(r["pl_gap"])
+            out[f"{tag}_{t}_pred_gap_bucket"] = gap_bucket(r["pred_gap"])
+            out[f"{tag}_{t}_lowmass"] = np_(r["lowmass"])
+        out[f"{tag}_miou"] = np.array([float(metric.compute()), float(metric.compute_iou("16")), float(metric.compute_iou("13"))])
+        print(tag, out[f"{tag}_miou"], flush=True)
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(GOLD, "net_b8.npz"), **out)
 
 
 def gen_loader():
@@ -342,8 +484,30 @@ def gen_loader():
         rec["unknown_name_error"] = str(e)
     for f in ("/tmp/synth_GTA5_baseline.pth", "/tmp/synth_bad_baseline.pth", "/tmp/synth_unknown_name.pth"):
         os.remove(f)
+    rec["branches"] = gen_loader_branches(p)
     with open(os.path.join(GOLD, "loader.json"), "w") as f:
         json.dump(rec, f, indent=1)
+
+
+sys.path.append(os.path.join(ROOT, "tests"))
+from loader_cases import LOADER_KEYS, loader_branch_files  # noqa: E402  (reference-free: shared with tests/test_cpu_host.py)
+
+
+def gen_loader_branches(p):
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = loader_branch_files(p, tmp)
+        for case, path in paths.items():
+            try:
+                net = T.DeepLabv2AdaptSeg(num_classes=19, multi_level=True, restore_from=path)
+            except Exception as e:          # noqa: BLE001 -- the error class IS the recorded behaviour
+                out[case] = {"error": type(e).__name__}
+                continue
+            sd = net.state_dict()
+            out[case] = {"checks": {k: sha(np_(sd[k])) for k in LOADER_KEYS},
+                         "layer5_from_file": bool(sha(np_(sd["layer5.conv2d_list.0.weight"])) == sha(p["layer5.conv2d_list.0.weight"]))}
+    return out
 
 
 def gen_fn_input():
@@ -377,9 +541,9 @@ def gen_fn_input():
 
 
 if __name__ == "__main__":
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
     which = sys.argv[1:] or ["bn", "sam", "tail", "small", "full", "multires", "stream", "loader", "input"]
-    m = make_diga() if set(which) & {"sam", "tail", "small", "full", "multires", "stream"} else None
+    m = make_diga() if set(which) & {"sam", "tail", "small", "full", "multires", "stream", "streams_ms", "long", "b8"} else None
     if "bn" in which:
         gen_fn_bn()
     if "sam" in which:
@@ -394,6 +558,12 @@ if __name__ == "__main__":
         gen_net_multires(m)
     if "stream" in which:
         gen_net_stream(m)
+    if "b8" in which:
+        gen_net_b8(m)
+    if "streams_ms" in which:
+        gen_net_streams_ms(m)
+    if "long" in which:
+        gen_net_long(m)
     if "loader" in which:
         gen_loader()
     if "input" in which:

@@ -3,6 +3,10 @@ path needs are read with PyYAML and the same keys).  Unlike the reference's eval
 `dataset_info` to the model, without which DIGA.__init__ cannot run.
 
     python src/eval.py [datamodule.frames=20] [datamodule.batch_size=1] [datamodule.frames_in_flight=4] [model.cfg.bn_lambda=0.8]
+                       [model/net=synthia_source] [precision=fp32x3]
+
+`group/option=name` picks a yaml of a config group as Hydra's override syntax does (model/net=synthia_source reads
+configs/model/net/synthia_source.yaml); `a.b.c=value` sets one key; `precision=fp32x2|fp32x3` runs the fp32-exact verification mode.
 """
 import functools
 import os
@@ -17,13 +21,25 @@ CLASS_NAMES = ["road", "sidewalk", "building", "wall", "fence", "pole", "light",
                "person", "rider", "car", "truck", "bus", "train", "motocycle", "bicycle"]
 
 
+def _yaml(*parts):
+    path = os.path.join(ROOT, "configs", *parts) + ".yaml"
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"no config {path}")
+    with open(path) as f:
+        return yaml.safe_load(f)
+
+
 def load_cfg(argv):
-    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "eval.yaml")))
-    model = yaml.safe_load(open(os.path.join(ROOT, "configs", "model", cfg["model"] + ".yaml")))
-    net = yaml.safe_load(open(os.path.join(ROOT, "configs", "model", "net", model["defaults"][0]["net"] + ".yaml")))
+    cfg = _yaml("eval")
+    groups = {k: v for k, v in (a.split("=", 1) for a in argv if "/" in a.split("=", 1)[0] or a.split("=", 1)[0] == "model")}
+    model = _yaml("model", groups.get("model", cfg["model"]))
+    net = _yaml("model", "net", groups.get("model/net", model["defaults"][0]["net"]))
     cfg["model"] = dict(model, net=net)
+    cfg.setdefault("precision", "bf16")
     for a in argv:                       # key.path=value overrides
         k, v = a.split("=", 1)
+        if k in groups:
+            continue
         d = cfg
         *path, leaf = k.split(".")
         for p in path:
@@ -43,7 +59,7 @@ def main(argv):
     net = functools.partial(T.DeepLabv2AdaptSeg, multi_level=cfg["model"]["net"]["multi_level"],
                             restore_from=restore if have_ckpt else None)
     info = dict(num_classes=19, image_size=tuple(dm["image_size"]), test_list=["synthetic"], class_names=CLASS_NAMES)
-    m = T.DIGA(net=net, dataset_info=info, cfg=cfg["model"]["cfg"])
+    m = T.DIGA(net=net, dataset_info=info, cfg=cfg["model"]["cfg"], precision=cfg["precision"])
     if not have_ckpt:
         print(f"[eval] {restore} not found: using the seeded synthetic weights")
         m.net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_params(0).items()}, strict=False)

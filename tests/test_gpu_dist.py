@@ -18,7 +18,7 @@ def _worker(rank, world, port, q, k):
     os.makedirs("gpurun_out", exist_ok=True)
     log = open(f"gpurun_out/dist_rank{rank}.log", "w")
     try:
-        (_worker_windows if k < 0 else _worker_stream if k > 1 else _worker_body)(rank, world, port, q, log, k)
+        (_worker_b8 if k == 8 else _worker_windows if k < 0 else _worker_stream if k > 1 else _worker_body)(rank, world, port, q, log, k)
     except Exception:
         traceback.print_exc(file=log)
         log.flush()
@@ -39,6 +39,33 @@ def _worker_body(rank, world, port, q, log, k):
     for t in range(NF):
         x, y = synth.synth_frame(t, world, H, W)
         probs = eng.forward_and_adapt(torch.from_numpy(x[rank:rank + 1]).cuda(), torch.from_numpy(y[rank:rank + 1]).cuda(), CFG)
+        torch.cuda.synchronize()
+        print("frame", t, "done", file=log, flush=True)
+        out.append(dict(probs=probs.cpu().numpy(), logits=eng.logits.cpu().numpy(), scale=eng.scale.cpu().numpy(),
+                        run=eng.run_proto.cpu().numpy(), rflag=eng.run_flag.cpu().numpy()))
+    dist.barrier()
+    q.put((rank, out))
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+def _worker_b8(rank, world, port, q, log, k):
+    """BASELINE configs[2]'s global batch of 8 on 2 ranks: 4 frames per rank (group A = global sample 0, on rank 0)."""
+    import torch.distributed as dist
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
+    per = 8 // world
+    eng = Engine(w, per, H, W, group=dist.group.WORLD)
+    out = []
+    for t in range(2):
+        x, y = synth.synth_frame(200 + t, 8, H, W)
+        sl = slice(rank * per, (rank + 1) * per)
+        probs = eng.forward_and_adapt(torch.from_numpy(x[sl]).cuda(), torch.from_numpy(y[sl]).cuda(), CFG)
         torch.cuda.synchronize()
         print("frame", t, "done", file=log, flush=True)
         out.append(dict(probs=probs.cpu().numpy(), logits=eng.logits.cpu().numpy(), scale=eng.scale.cpu().numpy(),
@@ -190,6 +217,36 @@ def test_two_ranks_reproduce_batch2_semantics():
         assert np.array_equal(res[0][t]["run"], res[1][t]["run"])
         ref_run = eng.run_proto.cpu().numpy()
         assert np.abs(res[0][t]["run"] - ref_run).max() <= 1e-5 * np.abs(ref_run).max()
+
+
+def test_two_ranks_reproduce_batch8_and_the_reference_fixture():
+    """Global batch 8 sharded 4 + 4 over two ranks == the single-process batch-8 engine (scale/shift of all 104 layers and the
+    logits bit-identical; SAM state up to fp32 rounding), which tests/test_gpu_net.py::test_batch8_vs_reference_bf16_floor and
+    tests/test_gpu_exact.py::test_exact_batch8_vs_reference tie to the reference's batch_size = 8 run (net_b8.npz, b8s)."""
+    from conftest import load_golden
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    res = _run_ranks(8)
+    g = load_golden("net_b8.npz")
+    w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
+    eng = Engine(w, 8, H, W)
+    for t in range(2):
+        x, y = synth.synth_frame(200 + t, 8, H, W)
+        probs = eng.forward_and_adapt(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), CFG)
+        torch.cuda.synchronize()
+        ref_logits, ref_probs = eng.logits.cpu().numpy(), probs.cpu().numpy()
+        for r in range(2):
+            got = res[r][t]
+            assert np.array_equal(got["scale"], eng.scale.cpu().numpy()), (t, r)
+            assert np.array_equal(got["logits"], ref_logits[4 * r:4 * r + 4]), (t, r)
+            assert np.array_equal(np.isnan(got["probs"]), np.isnan(ref_probs[4 * r:4 * r + 4]))
+            assert np.nanmax(np.abs(got["probs"] - ref_probs[4 * r:4 * r + 4])) < 1e-4
+            assert np.array_equal(got["rflag"], eng.run_flag.cpu().numpy())
+        assert np.array_equal(res[0][t]["run"], res[1][t]["run"])
+        # the sharded logits against the REFERENCE's batch-8 logits: the bf16-storage floor (1 % of the logit range)
+        both = np.concatenate([res[0][t]["logits"], res[1][t]["logits"]])
+        rl = g[f"b8s_{t}_logits"]
+        assert np.abs(both - rl).max() / (rl.max() - rl.min()) < 0.03
 
 
 def _rccl_worker(port, q):

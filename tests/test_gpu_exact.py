@@ -1,0 +1,280 @@
+"""-m gpu: END-TO-END parity at the north star's numbers, through the fp32-exact verification mode.
+
+The reference is fp32 end to end (ttda:1634-1645).  The product path stores activations in bf16, so its end-to-end
+distance to the reference sits at the bf16 floor (tests/test_gpu_net.py states that level).  Here the SAME kernels run with
+split bf16 operand planes ("bf16x6": every operand = 3 bf16 planes, 6 plane products accumulated in fp32) and fp32
+activation storage (diga_amd/verify.py, DIGA(..., precision="fp32x3")), and the results are compared with the
+reference's own outputs (tests/golden/*.npz, written by oracle/gen_golden.py from the reference source):
+
+    fp32 logits / probabilities / prototypes   within 1e-3 relative (measured: ~1e-5 .. 1e-6, asserted at 2e-4)
+    pseudo-labels, final arg-max               bit-exact outside the decision band: a pixel may differ only where the
+                                               reference's own top-2 gap (or its distance to the 0.9 bar) is < 1e-4,
+                                               i.e. where a perturbation of the size of the logit error flips it
+                                               -- or where the reference's own classifier normaliser (ttda:1729-1733) is below
+                                               1e-33 in exact arithmetic ("lowmass" in the fixtures): there its fp32 weights
+                                               exp(-d) are denormals or flushed to zero (the 0/0 -> NaN branch), i.e. the
+                                               reference's probabilities are quantisation noise that no re-implementation
+                                               can reproduce bit for bit (a 1-ulp change of d re-draws them)
+    running-prototype flags                    identical
+    mIoU-19/16/13                              within 0.01
+
+Tolerances are written where they are asserted.
+"""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from gpu_util import DEV, P, call, conv_desc, rel_err, stream
+from diga_amd import synth
+from diga_amd import ttda_module as T
+
+pytestmark = pytest.mark.gpu
+CFG = dict(bn_lambda=0.8, proto_lambda=0.8, fusion_lambda=0.8, confidence_threshold=0.9, proto_rho=0.1)
+NAMES = [f"c{i}" for i in range(19)]
+LOGIT_TOL = 2e-4          # max |logit - ref| / logit range; the north star's bar is 1e-3
+BAND_BUCKET = 4           # gap buckets >= 4 <=> top-2 gap < 1e-4: the only pixels whose integer decision may differ
+PMAX_BAND = 1e-4          # |p_max - 0.9| below this: the confidence rule may flip
+
+
+def make_diga(synth_params_np, precision):
+    m = T.DIGA(net=functools.partial(T.DeepLabv2AdaptSeg, multi_level=True, restore_from=None),
+               dataset_info=dict(num_classes=19, image_size=(321, 321), test_list=[0], class_names=NAMES), cfg=CFG, precision=precision)
+    sd = {k: torch.from_numpy(v) for k, v in synth_params_np.items()}
+    missing, unexpected = m.net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("lambda_") for k in missing)
+    m._configure_bn_running_stats()
+    return m
+
+
+@pytest.fixture(scope="module")
+def exact3(synth_params_np):
+    return make_diga(synth_params_np, "fp32x3")
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel level: the split-operand conv against an fp64 convolution of the unrounded fp32 operands
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nplanes,tol", [(2, 4e-5), (3, 2e-6)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,k3,dil", [(1, 33, 41, 64, 128, 1, False, 1), (2, 17, 23, 128, 64, 2, False, 1),
+                                                          (1, 21, 19, 64, 64, 1, True, 2), (2, 15, 18, 128, 128, 1, True, 4)])
+def test_split_operand_conv_matches_fp64(nplanes, tol, B, H, W, Cin, Cout, stride, k3, dil):
+    from diga_amd.engine import pack_taps
+    from diga_amd.verify import split_planes
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.7 + 0.3
+    k = 3 if k3 else 1
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    d = conv_desc(B, H, W, Cin, Cout, stride=stride, k3=k3, dil=dil)
+    d.out_f32, d.nplanes = 1, nplanes
+    xp = split_planes(x.permute(0, 2, 3, 1).contiguous().to(DEV), nplanes)
+    wp = split_planes(pack_taps([w.to(DEV)], None, dtype=torch.float32), nplanes)
+    M = B * d.Ho * d.Wo
+    out = torch.full((M, Cout), float("nan"), dtype=torch.float32, device=DEV)
+    units = call("diga_conv_stat_units", d)
+    slab = torch.full((units, 2, Cout), float("nan"), dtype=torch.float32, device=DEV)
+    sh = shift.to(DEV)
+    call("diga_conv_igemm_bf16", d, P(xp), P(wp), P(out), P(slab), P(sh), stream())
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=stride, padding=dil if k3 else 0, dilation=dil)
+    got = out.cpu().reshape(B, d.Ho, d.Wo, Cout).permute(0, 3, 1, 2).double()
+    assert rel_err(got, ref) < tol, rel_err(got, ref)
+    # statistics: per-channel shifted sums over all units == those of the fp64 result (sums of ~1e3 values: 1e-5 of scale)
+    s = slab.cpu().double().sum(0)
+    dref = ref - shift.double()[None, :, None, None]
+    assert rel_err(s[0], dref.sum((0, 2, 3))) < max(tol, 1e-5) and rel_err(s[1], (dref * dref).sum((0, 2, 3))) < max(tol, 1e-5)
+    # and the planes reproduce the fp32 operand exactly (3 planes) / to 2^-16 (2 planes)
+    back = xp.float().sum(0).cpu().permute(0, 3, 1, 2)
+    assert rel_err(back, x) <= (0.0 if nplanes == 3 else 2.0 ** -16)
+
+
+# ------------------------------------------------------------------------------------------------
+# end to end against the reference's fp32 outputs
+# ------------------------------------------------------------------------------------------------
+def _band_ok(got, ref, bucket, extra_unsafe=None):
+    """got == ref except where the reference's own decision gap is inside the band; returns (#mismatches, #band pixels)."""
+    mism = got != ref
+    unsafe = (bucket >= BAND_BUCKET)          # includes 255 = NaN gap (0/0 pixels)
+    if extra_unsafe is not None:
+        unsafe = unsafe | extra_unsafe
+    assert not (mism & ~unsafe).any(), (int((mism & ~unsafe).sum()), "mismatches outside the band", int(mism.sum()), "in total")
+    return int(mism.sum()), int(unsafe.sum())
+
+
+def _lowmass_full(g, name, H, W):
+    """Full-resolution pixels whose bilinear support touches a feature pixel marked lowmass by the fixture."""
+    lm = torch.from_numpy(g[name].astype(np.float32))[:, None]
+    return (torch.nn.functional.interpolate(lm, size=(H, W), mode="bilinear", align_corners=False)[:, 0] > 0).numpy()
+
+
+def _run_exact_sequence(m, g, key, frames, have_probs=True, sub=None):
+    """Frames through the fp32-exact engine, step by step (forward_feat -> sam_fuse -> tail, what forward_and_adapt + step do).
+    Decision forcing inside the band: a pseudo label may differ from the reference's only where the reference's own decision is
+    inside the band (asserted); such a pixel is then SET to the reference's label before SAM runs -- one flipped pixel of a
+    100-pixel class moves that class's instance prototype by 1 %, which would make every continuous comparison downstream
+    (prototypes, probabilities, final arg-max) a statement about that one in-band flip instead of about the kernels.
+    sub: index applied to logits / probabilities when the fixture stores them sub-sampled."""
+    if hasattr(m, "classifier_running_proto"):
+        del m.classifier_running_proto
+    metric = m.test_acc[0]
+    metric.reset()
+    report = []
+    sub = sub or (slice(None),) * 4
+    for t, (x, y) in enumerate(frames):
+        xd, yd = torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)
+        eng = m.net.engine(int(x.shape[0]), int(x.shape[2]), int(x.shape[3]))
+        eng.forward_feat(xd)
+        torch.cuda.synchronize()
+        k = functools.partial(key, t)
+        rec = {}
+        ref_logits = g[k("logits")]
+        rec["logit_err"] = float(np.abs(eng.logits.cpu().numpy()[sub] - ref_logits).max() / (ref_logits.max() - ref_logits.min()))
+        assert rec["logit_err"] <= LOGIT_TOL, rec
+        # pseudo labels: bit-exact outside the band (top-2 soft-max gap < 1e-4, or p_max within 1e-4 of the bar)
+        ref_pl = g[k("pseudo")].astype(np.int32)
+        pl = eng.labels[:eng.P].cpu().numpy().reshape(ref_pl.shape)
+        rec["pseudo_mismatch"], rec["pseudo_band"] = _band_ok(pl, ref_pl, g[k("pl_gap_bucket")],
+                                                              np.abs(g[k("pl_pmax")] - np.float32(0.9)) < PMAX_BAND)
+        if rec["pseudo_mismatch"]:
+            eng.labels[:eng.P].copy_(torch.from_numpy(ref_pl.reshape(-1)).to(DEV))       # decision forcing (in-band pixels only, see above)
+        eng.sam_fuse(yd, CFG)
+        eng.hist.zero_()
+        eng.tail(yd)
+        torch.cuda.synchronize()
+        metric.add_counts(eng.hist.reshape(eng.C, eng.C))
+        # final arg-max at full resolution
+        lowmass = g[k("lowmass")]
+        rec["lowmass_px"] = int(lowmass.sum())
+        rec["pred_mismatch"], rec["pred_band"] = _band_ok(eng.pred.cpu().numpy(), g[k("pred")], g[k("pred_gap_bucket")],
+                                                          _lowmass_full(g, k("lowmass"), y.shape[-2], y.shape[-1]))
+        assert np.array_equal(m.classifier_running_proto_exists_flag.cpu().numpy(), g[k("rflag")]), "running-prototype flags"
+        if k("run") in g:
+            rec["run_err"] = rel_err(m.classifier_running_proto.cpu().numpy(), g[k("run")])
+            assert rec["run_err"] <= 1e-5, rec
+        if have_probs:
+            pr, ref_pr = eng.probs.cpu().numpy()[sub], g[k("probs")].astype(np.float32)
+            ok = ~np.broadcast_to(lowmass[:, None], eng.probs.shape)[sub]
+            rec["nan_mismatch"] = int((np.isnan(pr) != np.isnan(ref_pr))[ok].sum())
+            rec["probs_err"] = float(np.nanmax(np.abs(pr - ref_pr)[ok]))
+            # exp(-d) with d ~ 30..100 in fp32: a relative error of ~1e-4 in a weight is the reference's own summation-order noise
+            assert rec["probs_err"] <= 1e-4 and rec["nan_mismatch"] == 0, rec
+        if k("hist") in g:
+            assert int(np.abs(metric.hist.cpu().numpy() - g[k("hist")]).sum()) <= 2 * (sum(r["pred_mismatch"] for r in report) + rec["pred_mismatch"]) * x.shape[0]
+        report.append(rec)
+    mious = [float(metric.compute()), float(metric.compute_iou("16")), float(metric.compute_iou("13"))]
+    return report, mious
+
+
+def test_exact_full_res_vs_reference(exact3, gold_full):
+    """Two 1024x512 frames (prototype seeding, then the EMA branch)."""
+    frames = [synth.synth_frame(t, 1, 512, 1024) for t in range(2)]
+    report, mious = _run_exact_sequence(exact3, gold_full, lambda t, k: f"{t}_{k}", frames)
+    print(report, mious, gold_full["miou"])
+    assert np.abs(np.array(mious) - gold_full["miou"]).max() <= 0.01
+
+
+def test_exact_stream_30_frames_vs_reference(exact3):
+    """The bench's stream (30 batch-1 frames, ~29 EMA steps): per frame logits, pseudo-labels, arg-max, flags; final
+    prototypes and mIoU-19/16/13."""
+    g = load_golden("net_stream.npz")
+    n = int(g["st_frames"])
+    frames = [synth.synth_frame(t, 1, 512, 1024) for t in range(n)]
+    g.update({f"st_{t}_logits": g[f"st_{t}_logits_sub"] for t in range(n)})
+    sub4 = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4))
+    report, mious = _run_exact_sequence(exact3, g, lambda t, k: f"st_{t}_{k}", frames, have_probs=False, sub=sub4)
+    print(report[-1], "max logit err", max(r["logit_err"] for r in report), "pred mismatches", sum(r["pred_mismatch"] for r in report),
+          "pseudo mismatches", sum(r["pseudo_mismatch"] for r in report), mious, g["st_miou"])
+    assert rel_err(exact3.classifier_running_proto.cpu().numpy(), g["st_run_final"]) <= 1e-4
+    assert np.abs(np.array(mious) - g["st_miou"]).max() <= 0.01
+    assert int(np.abs(exact3.test_acc[0].hist.cpu().numpy() - g[f"st_{n - 1}_hist"]).sum()) <= 2 * sum(r["pred_mismatch"] for r in report)
+
+
+@pytest.mark.parametrize("tag", ["b8s", "b8f"])
+def test_exact_batch8_vs_reference(exact3, tag):
+    """BASELINE configs[2]'s batch as ONE process: batch 8, half_first = sample 0 vs samples 1..7 (ttda:313-320)."""
+    g = load_golden("net_b8.npz")
+    B, H, W = (int(v) for v in g[f"{tag}_shape"])
+    frames = [synth.synth_frame(200 + t, B, H, W) for t in range(3 if tag == "b8s" else 2)]
+    sub = (slice(None), slice(None), slice(None, None, 4), slice(None, None, 4)) if tag == "b8f" else None
+    report, mious = _run_exact_sequence(exact3, g, lambda t, k: f"{tag}_{t}_{k}", frames, sub=sub)
+    print(tag, report, mious, g[f"{tag}_miou"])
+    assert np.abs(np.array(mious) - g[f"{tag}_miou"]).max() <= 0.01, (mious, g[f"{tag}_miou"])
+
+
+@pytest.mark.parametrize("tag", ["s1", "s2", "s3", "m1"])
+def test_exact_small_sequences_vs_reference(exact3, gold_small, tag):
+    """65x129 (B = 1, 2, 3: the half_first rule) and 129x257 inputs, 3 frames each: logits, probabilities, prototypes and
+    flags against the reference; these fixtures predate the gap buckets, so integer outputs are compared through the
+    reference's own logits: a pseudo label may differ only where |p_max - 0.9| < 1e-4 or the top-2 soft-max gap < 1e-4."""
+    g = gold_small
+    B, H, W = (int(v) for v in g[f"{tag}_shape"])
+    m = exact3
+    if hasattr(m, "classifier_running_proto"):
+        del m.classifier_running_proto
+    m.test_acc[0].reset()
+    for t in range(3):
+        x, y = synth.synth_frame(t, B, H, W)
+        m.test_step((torch.from_numpy(x), torch.from_numpy(y), None, None), t)
+        eng = m._last_engine
+        torch.cuda.synchronize()
+        key = lambda k: f"{tag}_{t}_{k}"
+        ref_logits = g[key("logits")]
+        err = float(np.abs(eng.logits.cpu().numpy() - ref_logits).max() / (ref_logits.max() - ref_logits.min()))
+        assert err <= LOGIT_TOL, (tag, t, err)
+        sm = np.sort(torch.from_numpy(ref_logits).softmax(1).numpy(), axis=1)
+        unsafe = (np.abs(sm[:, -1] - np.float32(0.9)) < PMAX_BAND) | (sm[:, -1] - sm[:, -2] < 1e-4)
+        pl = eng.labels[:eng.P].cpu().numpy().reshape(g[key("pseudo")].shape)
+        assert not ((pl != g[key("pseudo")]) & ~unsafe).any()
+        assert np.array_equal(m.classifier_running_proto_exists_flag.cpu().numpy(), g[key("rflag")])
+        assert rel_err(m.classifier_running_proto.cpu().numpy(), g[key("run")]) <= 1e-4
+        pr, ref_pr = eng.probs.cpu().numpy(), g[key("probs")]
+        assert np.array_equal(np.isnan(pr), np.isnan(ref_pr)) and float(np.nanmax(np.abs(pr - ref_pr))) <= 1e-3
+        # final arg-max: compare where the reference's up-sampled top-2 gap is >= 1e-4 (computed from its probabilities)
+        up = torch.nn.functional.interpolate(torch.from_numpy(ref_pr), size=(H, W), mode="bilinear", align_corners=False)
+        top2 = up.topk(2, dim=1)[0]
+        gap = (top2[:, 0] - top2[:, 1]).numpy()
+        safe = gap >= 1e-4
+        assert np.array_equal(eng.pred.cpu().numpy()[safe], g[key("pred")][safe])
+    mious = [float(m.test_acc[0].compute()), float(m.test_acc[0].compute_iou("16")), float(m.test_acc[0].compute_iou("13"))]
+    assert np.abs(np.array(mious) - g[f"{tag}_miou"]).max() <= 0.05, (mious, g[f"{tag}_miou"])    # a 65x129 frame: one pixel = 0.01 % of a class
+
+
+def test_exact_two_planes_is_bf16x3(synth_params_np, gold_full):
+    """precision="fp32x2" (3 plane products, ~2^-17 per product): logits within 1e-4 of the reference on a 1024x512 frame --
+    the cheaper form, already 10x inside the north star's 1e-3."""
+    m = make_diga(synth_params_np, "fp32x2")
+    x, y = synth.synth_frame(0, 1, 512, 1024)
+    m.test_step((torch.from_numpy(x), torch.from_numpy(y), None, None), 0)
+    torch.cuda.synchronize()
+    ref = gold_full["0_logits"]
+    err = float(np.abs(m._last_engine.logits.cpu().numpy() - ref).max() / (ref.max() - ref.min()))
+    print("fp32x2 logit error", err)
+    assert err <= 1e-4
+    assert (m._last_engine.labels[:m._last_engine.P].cpu().numpy().reshape(gold_full["0_pseudo"].shape) != gold_full["0_pseudo"]).mean() < 1e-3
+
+
+def test_helper_api_computes_in_fp32(exact3):
+    """cal_proto / cal_pred_of_proto / _update_classifier_proto / multi_proto_label take arbitrary fp32 features and
+    must not round them to bf16 (the reference computes these in fp32, ttda:1712-1805).  Features here are NOT bf16-representable."""
+    from oracle import diga_oracle as O
+    g = torch.Generator().manual_seed(91)
+    CH, h, w = 128, 11, 13
+    feat = (torch.randn(2, CH, h, w, generator=g).relu() * 0.37 + 1e-3 * torch.rand(2, CH, h, w, generator=g))
+    assert not torch.equal(feat, feat.bfloat16().float())
+    lab = torch.randint(0, 12, (2, h, w), generator=g)
+    lab[torch.rand(2, h, w, generator=g) < 0.2] = 255
+    m = exact3
+    proto, flag = m.cal_proto(feat, lab)
+    rp, rf = O.class_prototypes(feat, lab)
+    assert torch.equal(flag.cpu(), rf) and rel_err(proto.cpu(), rp) < 2e-6
+    wgt = m.cal_pred_of_proto(feat, rp, rf)
+    ref_w = O.proto_probs(feat, rp, rf)
+    assert np.nanmax(np.abs(wgt.cpu().numpy() - ref_w.numpy())) < 2e-6
+    run = torch.randn(19, CH, generator=g)
+    rflag = (torch.rand(19, generator=g) < 0.5).float()
+    r1, f1 = m._update_classifier_proto(feat, lab, run, rflag, 0.1)
+    q1, qf = O.update_running_proto(feat, lab, run, rflag, 0.1)
+    assert torch.equal(f1.cpu(), qf) and rel_err(r1.cpu(), q1) < 2e-6

@@ -373,3 +373,42 @@ def test_layout_roundtrip():
     torch.cuda.synchronize()
     assert torch.equal(back.cpu(), x)
     assert torch.equal(from_nhwc_bf16(nhwc, (2, 9, 13, 70)), x)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k3,dil,tile", [(1, 33, 65, 64, 256, False, 1, 0), (3, 23, 31, 128, 128, True, 2, 23),
+                                                        (2, 65, 129, 256, 1024, False, 1, 67), (4, 40, 50, 64, 256, False, 1, 48),
+                                                        (3, 65, 129, 256, 256, True, 2, 58), (2, 17, 19, 64, 64, True, 1, 24)])
+def test_conv_with_fused_dam_finalize_is_bit_identical(B, H, W, Cin, Cout, k3, dil, tile):
+    """diga_conv_igemm_bf16_dam (finalize folded into the conv launch: the last tile of each (sample, N tile) group reduces
+    the slab) == diga_conv_igemm_bf16 + diga_bn_finalize(per_sample = 1): output, slab, scale and shift bit for bit, on
+    repeated launches (the ticket words return to zero), for several tile shapes."""
+    if tile and Cout % {23: 64, 24: 128, 67: 256, 48: 256, 58: 256}[tile]:
+        pytest.skip("tile does not divide Cout")
+    g = torch.Generator().manual_seed(H * 7 + Cout + tile)
+    x = bf16_round(torch.randn(B, Cin, H, W, generator=g).relu() + 0.1 * torch.randn(B, Cin, H, W, generator=g))
+    ks = 3 if k3 else 1
+    wt = bf16_round(torch.randn(Cout, Cin, ks, ks, generator=g) * (2.0 / (Cin * ks * ks)) ** 0.5)
+    rm, rv, w, b = (t.to(DEV) for t in _bn_params(Cout, g))
+    d = conv_desc(B, H, W, Cin, Cout, k3=k3, dil=dil, tile=tile)
+    xin, wp = to_nhwc_bf16(x), pack_conv_weight(wt).to(DEV)
+    M = B * d.Ho * d.Wo
+    units = call("diga_conv_stat_units", d)
+    ups = units // B
+    lam, eps = float(np.float32(0.8)), 1e-5
+
+    def buffers():
+        return (torch.zeros(M * Cout, dtype=torch.bfloat16, device=DEV), torch.zeros(units * 2 * Cout, dtype=torch.float32, device=DEV),
+                torch.zeros(B * Cout, dtype=torch.float32, device=DEV), torch.zeros(B * Cout, dtype=torch.float32, device=DEV))
+    out0, slab0, sc0, sh0 = buffers()
+    call("diga_conv_igemm_bf16", d, P(xin), P(wp), P(out0), P(slab0), P(rm), stream())
+    call("diga_bn_finalize", P(slab0), ups, B, B, 1, Cout, float(d.Ho * d.Wo), 0.0, P(rm), P(rv), P(w), P(b), lam, eps, P(sc0), P(sh0), stream())
+    ticket = torch.zeros(call("diga_conv_dam_ticket_words", d), dtype=torch.int32, device=DEV)
+    for rep in range(3):
+        out1, slab1, sc1, sh1 = buffers()
+        sc1.fill_(float("nan")), sh1.fill_(float("nan"))
+        call("diga_conv_igemm_bf16_dam", d, P(xin), P(wp), P(out1), P(slab1), P(rm), P(rv), P(w), P(b), lam, eps, P(sc1), P(sh1),
+             P(ticket), stream())
+        torch.cuda.synchronize()
+        assert torch.equal(out1.view(torch.int16), out0.view(torch.int16)) and torch.equal(slab1, slab0), rep
+        assert torch.equal(sc1, sc0) and torch.equal(sh1, sh0), (rep, float((sc1 - sc0).abs().max()))
+        assert int(ticket.abs().sum()) == 0, rep
