@@ -37,6 +37,7 @@ SIGNATURES = {
     "diga_conv_igemm_bf16": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "diga_conv_dam_ticket_words": (_i, [C.POINTER(ConvDesc)]),
     "diga_conv_igemm_bf16_dam": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "diga_conv_igemm_bf16_fused_in": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "diga_conv_igemm_bf16_apply": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "diga_stem_conv7x7s2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "diga_bn_finalize": (_i, [_vp, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),

@@ -53,6 +53,15 @@ struct ConvKParams {
   int term_ab[6];
   // fused DAM finalize (diga_conv_igemm_bf16_dam): the LAST tile to finish of each (sample, N tile) group reduces that
   // sample's slab columns [n0, n0 + BN) exactly as diga_bn_finalize(per_sample) does and writes scale / shift.
+  // fused DAM apply on the INPUT operand (diga_conv_igemm_bf16_fused_in, AMODE > 0): `in` is the producer's RAW bf16 output;
+  // A = bf16(relu(fma(raw, a_scale[c], a_shift[c]) [+ a_res])) is formed in registers on its way to LDS (the arithmetic of
+  // bn_apply_kernel<0> / <1>), so the normalised activation is never written and read back.  AMODE 2 (1x1 convs) also
+  // writes A to a_out -- the block input the NEXT residual needs -- from the N-tile-0 blocks.
+  const float* a_scale;      // [Cin] or [samples][Cin] (a_affine_stride = Cin)
+  const float* a_shift;
+  const void* a_res;         // bf16 [rows][Cin], AMODE 2
+  void* a_out;               // bf16 [rows][Cin], AMODE 2
+  int a_affine_stride;
   unsigned* fin_ticket;      // NULL = off; [samples * ntiles_n] counters, zero before the launch, left zero by it
   const float* fin_rvar;     // running_var, weight, bias [Cout] (running_mean = shift)
   const float* fin_weight;
@@ -78,8 +87,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // 5 = fp32 output + statistics (verification mode: nothing is rounded to bf16 between the accumulators and the next stage).
 enum { EPI_BF16_STATS = 0, EPI_F32 = 1, EPI_BF16 = 2, EPI_STATS_ONLY = 3, EPI_FUSED_APPLY = 4, EPI_F32_STATS = 5 };
 
-template <int BM, int BN, int WM, int WN, int S, int BK, bool ILV, int EPI>
+template <int BM, int BN, int WM, int WN, int S, int BK, bool ILV, int EPI, int AMODE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKParams p) {
+  static_assert(AMODE == 0 || (S == 2 && !ILV && EPI == EPI_BF16_STATS), "the fused-input path: 2-deep ring, burst issue, trunk epilogue");
   constexpr bool OUT_F32 = EPI == EPI_F32 || EPI == EPI_F32_STATS;
   constexpr bool STATS = EPI == EPI_BF16_STATS || EPI == EPI_STATS_ONLY || EPI == EPI_F32_STATS;
   constexpr int NW = WM * WN, NTHR = 64 * NW;        // 4 or 8 waves
@@ -164,6 +174,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     is_tap = q - is_chunk * p.ntaps;
   }
   int is_dd = p.dydx[is_tap];
+  // fused-input path (AMODE > 0): this lane's A chunks of the K step in flight, the step's channel affine, validity bits
+  [[maybe_unused]] u32x4 a_raw[A_CH], a_rsd[A_CH];
+  [[maybe_unused]] f32x4 a_sc[2], a_sh[2];
+  [[maybe_unused]] unsigned a_mask = 0u;
+  [[maybe_unused]] int a_tapoff = 0;
+  [[maybe_unused]] auto a_store = [&](int stage) {
+    // A = bf16(relu(fma(raw, scale, shift) [+ residual])): bn_apply_kernel's arithmetic, rounded once, exactly the value the
+    // unfused path stores and re-reads; out-of-image taps and rows beyond the sample stay zero (zero padding)
+    unsigned char* const dA = smem + stage * STAGE_BYTES + wave * 1024 + lane * 16;
+    const float sc[8] = {a_sc[0][0], a_sc[0][1], a_sc[0][2], a_sc[0][3], a_sc[1][0], a_sc[1][1], a_sc[1][2], a_sc[1][3]};
+    const float sh[8] = {a_sh[0][0], a_sh[0][1], a_sh[0][2], a_sh[0][3], a_sh[1][0], a_sh[1][1], a_sh[1][2], a_sh[1][3]};
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      float v[8], q[8];
+      unpack_bf16x8(a_raw[i], v);
+      if constexpr (AMODE == 2) unpack_bf16x8(a_rsd[i], q);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = fmaf(v[e], sc[e], sh[e]);
+        if constexpr (AMODE == 2) y += q[e];
+        v[e] = fmaxf(y, 0.f);
+      }
+      const bool ok = (a_mask >> i) & 1u;
+      const u32x4 o = ok ? pack_bf16x8(v) : u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(dA + i * NW * 1024) = o;
+      if constexpr (AMODE == 2) {
+        if (ok && ntile == 0) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.a_out) + (pixoff[i] + a_tapoff)) = o;
+      }
+    }
+  };
+
   // One K step's loads are LPT pieces (A pieces, then B pieces).  issue_pieces<lo, hi> issues pieces [lo, hi) of the next
   // K step; advance_next() moves on to the following step.  ILV kernels spread the pieces over the MFMA groups of the
   // running step (an LDS-DMA piece costs the issuing wave ~100 cycles: issued in one burst right after the barrier,
@@ -176,12 +217,34 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     const int tapoff = (dy * p.W + dx) * p.Cin + c0;
     unsigned char* const dA = smem + stage * STAGE_BYTES + wave * 1024;
     unsigned char* const dB = dA + A_BYTES;
+    if constexpr (AMODE > 0) {
+      // register-staged A: raw (+ residual) chunks and this K step's 8 channels of scale / shift; transformed and written to
+      // LDS by a_store() once they have landed
+      a_tapoff = tapoff;
+      a_mask = 0u;
+      const float* sp = p.a_scale + (size_t)n_img * p.a_affine_stride + c0 + cch * 8;
+      const float* hp = p.a_shift + (size_t)n_img * p.a_affine_stride + c0 + cch * 8;
+      a_sc[0] = *reinterpret_cast<const f32x4*>(sp), a_sc[1] = *reinterpret_cast<const f32x4*>(sp + 4);
+      a_sh[0] = *reinterpret_cast<const f32x4*>(hp), a_sh[1] = *reinterpret_cast<const f32x4*>(hp + 4);
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      if (i < lo || i >= hi) continue;
-      const bool ok = (unsigned)(ih0[i] + dy) < (unsigned)p.H && (unsigned)(iw0[i] + dx) < (unsigned)p.W;
-      const unsigned short* src = ok ? in + (pixoff[i] + tapoff) : zero;
-      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(dA + i * NW * 1024), 16, 0, 0);
+      for (int i = 0; i < A_CH; ++i) {
+        const bool ok = (unsigned)(ih0[i] + dy) < (unsigned)p.H && (unsigned)(iw0[i] + dx) < (unsigned)p.W;
+        a_mask |= ok ? 1u << i : 0u;
+        const unsigned short* src = ok ? in + (pixoff[i] + tapoff) : zero;
+        a_raw[i] = *reinterpret_cast<const u32x4*>(src);
+        if constexpr (AMODE == 2) {
+          const unsigned short* rsrc = ok ? reinterpret_cast<const unsigned short*>(p.a_res) + (pixoff[i] + tapoff) : zero;
+          a_rsd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rsrc));   // read for the last time
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        if (i < lo || i >= hi) continue;
+        const bool ok = (unsigned)(ih0[i] + dy) < (unsigned)p.H && (unsigned)(iw0[i] + dx) < (unsigned)p.W;
+        const unsigned short* src = ok ? in + (pixoff[i] + tapoff) : zero;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(dA + i * NW * 1024), 16, 0, 0);
+      }
     }
 #pragma unroll
     for (int j = 0; j < B_CH; ++j) {
@@ -235,6 +298,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     if (younger >= 2) wait_vmcnt<(D >= 3 ? 2 : 0) * LPT>();
     else if (younger == 1) wait_vmcnt<(D >= 2 ? 1 : 0) * LPT>();
     else wait_vmcnt<0>();
+    if constexpr (AMODE > 0) {          // this wave's A chunks of tile t have landed in registers: transform, write them to LDS
+      a_store(stage);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();       // every wave's part of tile t is in LDS; everyone is done reading tile t-1
     const bool more = t + D < nt;       // K step t+D refills the buffer tile t-1 was read from
     if (!ILV && more) issue_next(fill);
@@ -470,7 +537,9 @@ const TileCfg kTiles[] = {{1, 128, 128, 4}, {11, 128, 128, 3}, {21, 128, 128, 2}
                           {56, 256, 128, 4, 32, true}, {57, 128, 256, 4, 32, true}, {58, 256, 256, 4, 32, true},
                           // ids 6x: 32-channel steps with only 2 buffers -- half the LDS, so that two (four) blocks share a CU and
                           // one block's epilogue overlaps another's K loop (the short-K 1x1 convs: K = 256 is 4-8 steps per tile)
-                          {61, 128, 128, 2, 32, false}, {64, 64, 128, 2, 32, false}, {66, 256, 128, 2, 32, true}, {67, 128, 256, 2, 32, true}};
+                          {61, 128, 128, 2, 32, false}, {64, 64, 128, 2, 32, false}, {66, 256, 128, 2, 32, true}, {67, 128, 256, 2, 32, true},
+                          // ids 76 / 77: the shapes of 66 / 67 without interleaved issue -- the fused-input kernels only
+                          {76, 256, 128, 2, 32, false}, {77, 128, 256, 2, 32, false}};
 
 const TileCfg* find_tile(int id) {
   for (const auto& t : kTiles)
@@ -519,6 +588,27 @@ int launch_cfg(const ConvKParams& p, int splitk, int epi, hipStream_t st) {
   return DIGA_OK;
 }
 
+// The fused-input kernels (AMODE 1 / 2): trunk epilogue only, 2-deep ring, no interleaved issue.
+template <int BM, int BN, int WM, int WN, int BK>
+int launch_fused_in(const ConvKParams& p, int amode, hipStream_t st) {
+  constexpr int main_bytes = 2 * (BM + BN) * BK * 2;
+  constexpr int epi_bytes = BM * BN * 2;
+  constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  dim3 grid(p.mtiles * p.ntiles_n, 1), block(64 * WM * WN);
+#define DIGA_FUSED_KERNEL(A) conv_igemm_kernel<BM, BN, WM, WN, 2, BK, false, EPI_BF16_STATS, A>
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_FUSED_KERNEL(1)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&DIGA_FUSED_KERNEL(2)), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  });
+  if (amode == 1)
+    hipLaunchKernelGGL((DIGA_FUSED_KERNEL(1)), grid, block, smem, st, p);
+  else
+    hipLaunchKernelGGL((DIGA_FUSED_KERNEL(2)), grid, block, smem, st, p);
+#undef DIGA_FUSED_KERNEL
+  return DIGA_OK;
+}
+
 int validate(const diga_conv_desc* d, const char* who) {
   DIGA_CHECK_ARG(d != nullptr, "%s: desc is NULL", who);
   DIGA_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "%s: bad spatial dims", who);
@@ -549,6 +639,14 @@ extern "C" int diga_conv_stat_units(const diga_conv_desc* d) {
 }
 
 namespace {
+struct FusedIn {               // fused DAM apply on the input operand (diga_conv_igemm_bf16_fused_in); amode == 0: off
+  int amode = 0;
+  const float *scale = nullptr, *shift = nullptr;
+  const void* res = nullptr;
+  void* act_out = nullptr;
+  int affine_stride = 0;
+};
+
 struct FinArgs {               // fused DAM finalize (diga_conv_igemm_bf16_dam); ticket == nullptr: off
   unsigned* ticket = nullptr;
   const float *rvar = nullptr, *weight = nullptr, *bias = nullptr;
@@ -558,7 +656,7 @@ struct FinArgs {               // fused DAM finalize (diga_conv_igemm_bf16_dam);
 
 int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out, float* stat_slab, const float* stat_shift,
              int epi, const float* ep_scale, const float* ep_shift, const void* ep_res, int ep_affine_stride, int ep_relu,
-             void* stream, const FinArgs& fin = FinArgs()) {
+             void* stream, const FinArgs& fin = FinArgs(), const FusedIn& fi = FusedIn()) {
   const TileCfg* t = find_tile(d->tile ? d->tile : auto_tile(d));
   DIGA_CHECK_ARG(t != nullptr, "diga_conv_igemm_bf16: unknown tile id %d", d->tile);
   DIGA_CHECK_ARG(d->cout_pad % t->BN == 0, "diga_conv_igemm_bf16: cout_pad %d not a multiple of tile N %d", d->cout_pad, t->BN);
@@ -569,6 +667,7 @@ int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out
   p.slab = stat_slab;
   p.shift = stat_shift;
   p.ep_scale = ep_scale, p.ep_shift = ep_shift, p.ep_res = ep_res, p.ep_affine_stride = ep_affine_stride, p.ep_relu = ep_relu;
+  p.a_scale = fi.scale, p.a_shift = fi.shift, p.a_res = fi.res, p.a_out = fi.act_out, p.a_affine_stride = fi.affine_stride;
   p.fin_ticket = fin.ticket, p.fin_rvar = fin.rvar, p.fin_weight = fin.weight, p.fin_bias = fin.bias;
   p.fin_scale = fin.scale, p.fin_shift = fin.shift, p.fin_lam = fin.lam, p.fin_eps = fin.eps;
   p.fin_n = (double)d->Ho * d->Wo;
@@ -598,6 +697,25 @@ int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out
   }
   hipStream_t st = (hipStream_t)stream;
   int e = DIGA_OK;
+  if (fi.amode) {
+    switch (t->id) {
+      case 21: e = launch_fused_in<128, 128, 2, 2, 64>(p, fi.amode, st); break;
+      case 22: e = launch_fused_in<128, 64, 2, 2, 64>(p, fi.amode, st); break;
+      case 23: e = launch_fused_in<64, 64, 2, 2, 64>(p, fi.amode, st); break;
+      case 24: e = launch_fused_in<64, 128, 2, 2, 64>(p, fi.amode, st); break;
+      case 26: e = launch_fused_in<256, 128, 4, 2, 64>(p, fi.amode, st); break;
+      case 27: e = launch_fused_in<128, 256, 2, 4, 64>(p, fi.amode, st); break;
+      case 28: e = launch_fused_in<256, 256, 2, 4, 64>(p, fi.amode, st); break;
+      case 61: e = launch_fused_in<128, 128, 2, 2, 32>(p, fi.amode, st); break;
+      case 64: e = launch_fused_in<64, 128, 2, 2, 32>(p, fi.amode, st); break;
+      case 76: e = launch_fused_in<256, 128, 4, 2, 32>(p, fi.amode, st); break;
+      case 77: e = launch_fused_in<128, 256, 2, 4, 32>(p, fi.amode, st); break;
+      default: diga_set_error("diga_conv_igemm_bf16_fused_in: tile id %d has no fused-input kernel", t->id); return DIGA_EINVAL;
+    }
+    if (e) return e;
+    DIGA_CHECK_LAUNCH("diga_conv_igemm_bf16_fused_in");
+    return DIGA_OK;
+  }
 #define DIGA_TILE_CASES(base, BM, BN, WM, WN)                                                   \
   case base: e = launch_cfg<BM, BN, WM, WN, 4>(p, d->splitk, epi, st); break;          \
   case base + 10: e = launch_cfg<BM, BN, WM, WN, 3>(p, d->splitk, epi, st); break;     \
@@ -630,6 +748,7 @@ int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out
     case 64: e = launch_cfg<64, 128, 2, 2, 2, 32, false>(p, d->splitk, epi, st); break;
     case 66: e = launch_cfg<256, 128, 4, 2, 2, 32, true>(p, d->splitk, epi, st); break;
     case 67: e = launch_cfg<128, 256, 2, 4, 2, 32, true>(p, d->splitk, epi, st); break;
+    default: diga_set_error("diga_conv_igemm_bf16: tile id %d has no kernel for this entry point", t->id); return DIGA_EINVAL;
   }
 #undef DIGA_TILE_CASES
   if (e) return e;
@@ -675,4 +794,24 @@ extern "C" int diga_conv_igemm_bf16_dam(const diga_conv_desc* d, const void* in,
   fin.ticket = ticket, fin.rvar = running_var, fin.weight = weight, fin.bias = bias, fin.scale = scale, fin.shift = shift;
   fin.lam = lam, fin.eps = eps;
   return run_conv(d, in, wgt, out, stat_slab, running_mean, epi, nullptr, nullptr, nullptr, 0, 0, stream, fin);
+}
+
+extern "C" int diga_conv_igemm_bf16_fused_in(const diga_conv_desc* d, const void* raw_in, const float* in_scale, const float* in_shift,
+                                             const void* in_res, void* act_out, int nsamples_affine, const void* wgt, void* out,
+                                             float* stat_slab, const float* stat_shift, void* stream) {
+  if (int e = validate(d, "diga_conv_igemm_bf16_fused_in")) return e;
+  DIGA_CHECK_ARG(raw_in && in_scale && in_shift && wgt && out && stat_slab && stat_shift, "diga_conv_igemm_bf16_fused_in: NULL pointer");
+  DIGA_CHECK_ARG(!d->out_f32 && d->splitk == 1 && d->nplanes <= 1, "diga_conv_igemm_bf16_fused_in: bf16 output, no split-K, no operand planes");
+  DIGA_CHECK_ARG((in_res == nullptr) == (act_out == nullptr), "diga_conv_igemm_bf16_fused_in: in_res and act_out go together");
+  DIGA_CHECK_ARG(!in_res || (d->ntaps == 1 && d->stride == 1), "diga_conv_igemm_bf16_fused_in: the residual form is for 1x1 stride-1 convs");
+  DIGA_CHECK_ARG(nsamples_affine == 0 || nsamples_affine == d->B, "diga_conv_igemm_bf16_fused_in: nsamples_affine must be 0 or B");
+  FusedIn fi;
+  fi.amode = in_res ? 2 : 1;
+  fi.scale = in_scale, fi.shift = in_shift, fi.res = in_res, fi.act_out = act_out, fi.affine_stride = nsamples_affine ? d->Cin : 0;
+  if (d->tile == 0) {                 // auto rule of the fused-input kernels (the caller usually autotunes)
+    diga_conv_desc dd = *d;
+    dd.tile = d->cout_pad % 128 == 0 ? 21 : 23;
+    return run_conv(&dd, raw_in, wgt, out, stat_slab, stat_shift, EPI_BF16_STATS, nullptr, nullptr, nullptr, 0, 0, stream, FinArgs(), fi);
+  }
+  return run_conv(d, raw_in, wgt, out, stat_slab, stat_shift, EPI_BF16_STATS, nullptr, nullptr, nullptr, 0, 0, stream, FinArgs(), fi);
 }

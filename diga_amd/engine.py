@@ -145,7 +145,8 @@ class Engine:
 
     def __init__(self, weights: NetWeights, B: int, H: int, W: int, bn_lambda: float = 0.8, group=None,
                  confidence_threshold: float = 0.9, stream: bool = False, conv_tile: int = 0,
-                 autotune: bool = False, fuse_conv3: bool = False, force_exchange: bool = False, fold_finalize: bool = False):
+                 autotune: bool = False, fuse_conv3: bool = False, force_exchange: bool = False, fold_finalize: bool = False,
+                 fuse_apply="auto"):
         """stream=False: x is ONE batch of B samples -> the reference's batch semantics (half_first DAM statistics over
         the batch, prototypes pooled over the batch).  stream=True: x holds B CONSECUTIVE batch-1 frames of a stream
         ("frames in flight"): the trunk runs once over all of them with per-sample DAM statistics (DAM carries no
@@ -165,6 +166,21 @@ class Engine:
         # 629.1 frames/s -- the statistics pass runs at 770 TFLOP/s but the residual read in the fused epilogue is not
         # overlapped with the K loop (168 us against 133 + 131 us for conv3 + bn_apply), so it is off by default.
         self.fuse_conv3 = bool(fuse_conv3)
+        # fuse_apply: the DAM apply + ReLU of bn1 / bn2 runs on the operand path of conv2 / conv3 (act1 / act2 are never
+        # materialised), and "bn3 + residual + ReLU" of a block runs on the operand path of the NEXT block's conv1, which also
+        # writes the block input the next residual needs (diga_conv_igemm_bf16_fused_in).  Same arithmetic, same single bf16
+        # rounding: every tensor is bit-identical to the unfused path (tests/test_gpu_net.py).  Blocks with a downsample branch and
+        # the last block of a layer keep diga_bn_apply.
+        # fuse_apply = "conv1": only the residual form; "all": conv2 / conv3 too; False: every apply is its own launch; "auto"
+        # (default): "conv1" when the pass is large enough to be bandwidth-bound (>= 4 frames' worth of 1024x512 feature rows),
+        # else False.  Measured (same-box A/B, 15 frames in flight, one window, HIP-graph replay): False 22.17 ms, "conv1"
+        # 21.23 ms (+4.4 % frames/s: the fused conv1 costs +83 us and replaces a 131 us bn_apply), "all" 22.55 ms (conv2 / conv3
+        # slow down by 45 us each -- the transform runs 9x / 4x redundantly over taps / N tiles -- for a 25 us bn_apply each);
+        # one frame per step: 3.25 / 3.43 / 3.83 ms, the operand-path transform is exposed in a latency-bound K loop.
+        if fuse_apply == "auto":
+            fuse_apply = "conv1" if B * ((H + 7) // 8) * ((W + 7) // 8) >= 4 * 8385 else False
+        self.fuse_apply = False if self.fuse_conv3 else ("all" if fuse_apply is True else fuse_apply)
+        assert self.fuse_apply in (False, "conv1", "all"), fuse_apply
         # stream + group: the B local samples are this rank's frames of B consecutive GLOBAL batches (one frame per rank
         # per batch): statistics are exchanged per batch, so every global batch keeps the reference's batch semantics
         self.w = weights
@@ -306,18 +322,19 @@ class Engine:
         call("diga_bn_apply", _p(raw), _p(sc), _p(sh), _p(res), _p(rsc), _p(rsh), _p(out), M, Cc, 1,
              self.B if self.stream else 0, _stream())
 
-    def _conv_bn(self, name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn: BNP):
+    def _conv_bn(self, name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn: BNP, fused_in=None):
         """One trunk conv + its DAM finalize -> (scale, shift) of the BN layer that follows it."""
-        if self.fold_finalize:
+        if self.fold_finalize and fused_in is None:
             self._conv(name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn, fold=True)
             return self._affine(bn)
-        nt = self._conv(name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn)
+        nt = self._conv(name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn, fused_in=fused_in)
         return self._finalize(bn, nt, Ho * Wo)
 
-    def _conv(self, name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn: BNP | None, apply=None, fold=False):
+    def _conv(self, name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn: BNP | None, apply=None, fold=False, fused_in=None):
         """One trunk conv.  out=None: statistics only.  apply=(scale, shift, residual): pass 2 of a fused conv3
         (diga_conv_igemm_bf16_apply; no statistics).  fold: the DAM finalize runs inside the launch (per-sample statistics).
-        Returns the statistics units per sample."""
+        fused_in=(scale, shift, residual | None, act_out | None): x is the producer's RAW output and the DAM apply + ReLU
+        (+ residual) runs on the operand path (diga_conv_igemm_bf16_fused_in).  Returns the statistics units per sample."""
         d = ConvDesc()
         d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = self.B, Hin, Win, Cin, Ho, Wo, Cout
         d.stride = stride
@@ -330,7 +347,14 @@ class Engine:
         d.cout_pad = Cout
         d.splitk, d.out_f32, d.tile = 1, 0, self.conv_tile
         wgt = self.w.conv[name]
-        if apply is None and fold:
+        if fused_in is not None:
+            fsc, fsh, fres, fact = fused_in
+
+            def launch():
+                call("diga_conv_igemm_bf16_fused_in", C.byref(d), _p(x), _p(fsc), _p(fsh), _p(fres), _p(fact), self.B if self.stream else 0,
+                     _p(wgt), _p(out), _p(self.slab), _p(bn.running_mean), _stream())
+            mode = "fin2" if fres is not None else "fin1"
+        elif apply is None and fold:
             sc, sh = self._affine(bn)
             lam = self.lam if bn.lam is None else bn.lam
 
@@ -362,7 +386,7 @@ class Engine:
         self.conv_flops += flops
         return (Ho * Wo + 31) // 32          # statistics units per sample
 
-    TILE_CANDIDATES = {23: 64, 13: 64, 22: 64, 12: 64, 24: 128, 14: 128, 21: 128, 26: 128, 16: 128, 27: 256, 17: 256, 28: 256,
+    TILE_CANDIDATES = {76: 128, 77: 256, 23: 64, 13: 64, 22: 64, 12: 64, 24: 128, 14: 128, 21: 128, 26: 128, 16: 128, 27: 256, 17: 256, 28: 256,
                        33: 64, 32: 64, 34: 128, 31: 128, 36: 128, 37: 256, 38: 256,
                        46: 128, 47: 256, 48: 256, 56: 128, 57: 256, 58: 256, 61: 128, 64: 128, 66: 128, 67: 256}   # id -> N tile
 
@@ -423,6 +447,7 @@ class Engine:
              int(self.stream), _stream())
         self._tap("maxpool", cur, (B, self.h2, self.w2, 64))
         Hc, Wc, Cc = self.h2, self.w2, 64
+        pending = None          # (scale3, shift3, block name) of a block whose closing apply is deferred into the next conv1
         for li, (nb, pl, st, dil) in enumerate(zip(LAYERS, PLANES, STRIDES, DILATIONS), start=1):
             for b in range(nb):
                 pre = f"layer{li}.{b}"
@@ -430,31 +455,56 @@ class Engine:
                 Ho, Wo = (Hc - 1) // s + 1, (Wc - 1) // s + 1
                 M = B * Ho * Wo
                 rows = Ho * Wo
+                fuse = self.fuse_apply == "all"
                 # conv1 (1x1, carries the stride) -> bn1 -> relu
                 bn1 = w.bn[pre + ".bn1"]
-                sc, sh = self._conv_bn(pre + ".conv1", cur, self.raw1, Hc, Wc, Cc, Ho, Wo, pl, s, 1, False, bn1)
+                if pending is not None:
+                    # the previous block's "bn3 + residual + relu" on this conv's operand path; it writes the block input into nxt
+                    psc, psh, ppre = pending
+                    sc, sh = self._conv_bn(pre + ".conv1", self.raw3, self.raw1, Hc, Wc, Cc, Ho, Wo, pl, s, 1, False, bn1,
+                                           fused_in=(psc, psh, cur, nxt))
+                    cur, nxt = nxt, cur
+                    self._tap(ppre, cur, (B, Hc, Wc, Cc))
+                    pending = None
+                else:
+                    sc, sh = self._conv_bn(pre + ".conv1", cur, self.raw1, Hc, Wc, Cc, Ho, Wo, pl, s, 1, False, bn1)
                 self._tap(pre + ".conv1", self.raw1, (B, Ho, Wo, pl))
-                self._apply(self.raw1, sc, sh, None, None, None, self.act1, M, pl)
-                self._tap(pre + ".act1", self.act1, (B, Ho, Wo, pl))
                 # conv2 (3x3 dilated, pad = dilation) -> bn2 -> relu
                 bn2 = w.bn[pre + ".bn2"]
-                sc, sh = self._conv_bn(pre + ".conv2", self.act1, self.raw2, Ho, Wo, pl, Ho, Wo, pl, 1, dil, True, bn2)
+                if fuse:
+                    sc, sh = self._conv_bn(pre + ".conv2", self.raw1, self.raw2, Ho, Wo, pl, Ho, Wo, pl, 1, dil, True, bn2,
+                                           fused_in=(sc, sh, None, None))
+                else:
+                    self._apply(self.raw1, sc, sh, None, None, None, self.act1, M, pl)
+                    self._tap(pre + ".act1", self.act1, (B, Ho, Wo, pl))
+                    sc, sh = self._conv_bn(pre + ".conv2", self.act1, self.raw2, Ho, Wo, pl, Ho, Wo, pl, 1, dil, True, bn2)
                 self._tap(pre + ".conv2", self.raw2, (B, Ho, Wo, pl))
-                self._apply(self.raw2, sc, sh, None, None, None, self.act2, M, pl)
-                self._tap(pre + ".act2", self.act2, (B, Ho, Wo, pl))
                 # conv3 (1x1) -> bn3 (+ residual, relu)
                 bn3 = w.bn[pre + ".bn3"]
                 if self.fuse_conv3 and b != 0:
+                    self._apply(self.raw2, sc, sh, None, None, None, self.act2, M, pl)
+                    self._tap(pre + ".act2", self.act2, (B, Ho, Wo, pl))
                     sc3, sh3 = self._conv_bn(pre + ".conv3", self.act2, None, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)      # statistics
                     self._conv(pre + ".conv3", self.act2, nxt, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, None, apply=(sc3, sh3, cur))
                 else:
-                    sc3, sh3 = self._conv_bn(pre + ".conv3", self.act2, self.raw3, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)
+                    if fuse:
+                        sc3, sh3 = self._conv_bn(pre + ".conv3", self.raw2, self.raw3, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3,
+                                                 fused_in=(sc, sh, None, None))
+                    else:
+                        self._apply(self.raw2, sc, sh, None, None, None, self.act2, M, pl)
+                        self._tap(pre + ".act2", self.act2, (B, Ho, Wo, pl))
+                        sc3, sh3 = self._conv_bn(pre + ".conv3", self.act2, self.raw3, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)
                     self._tap(pre + ".conv3", self.raw3, (B, Ho, Wo, pl * 4))
                     if b == 0:    # downsample branch: 1x1 (stride) + bn on the block input
                         bnd = w.bn[pre + ".downsample.1"]
                         scd, shd = self._conv_bn(pre + ".downsample.0", cur, self.rawd, Hc, Wc, Cc, Ho, Wo, pl * 4, s, 1, False, bnd)
                         self._tap(pre + ".downsample.0", self.rawd, (B, Ho, Wo, pl * 4))
                         self._apply(self.raw3, sc3, sh3, self.rawd, scd, shd, nxt, M, pl * 4)
+                    elif self.fuse_apply and b < nb - 1:
+                        # deferred: the next block's conv1 applies bn3 + residual + relu while it loads its operand
+                        pending = (sc3, sh3, pre)
+                        Hc, Wc, Cc = Ho, Wo, pl * 4
+                        continue
                     else:
                         self._apply(self.raw3, sc3, sh3, cur, None, None, nxt, M, pl * 4)
                 cur, nxt = nxt, cur

@@ -85,6 +85,18 @@ int diga_conv_igemm_bf16_dam(const diga_conv_desc* desc, const void* in, const v
                              const float* running_mean, const float* running_var, const float* weight,
                              const float* bias, float lam, float eps, float* scale, float* shift,
                              uint32_t* ticket, void* stream);
+/* The same convolution (bf16 output + statistics) whose INPUT is the producer's RAW output: the DAM apply + ReLU of the previous
+ * BN layer runs on the operand path, A = bf16(relu(raw_in*in_scale[c] + in_shift[c] [+ in_res])), with the arithmetic and the
+ * single bf16 rounding of diga_bn_apply -- results are bit-identical to diga_bn_apply followed by diga_conv_igemm_bf16, but
+ * the normalised activation is never written and read back ("conv -> bn -> relu -> conv", adaptseg:85-93).
+ * in_res / act_out (both or neither; 1x1 stride-1 convs): the residual form relu(bn3(raw3) + x) that opens the NEXT bottleneck
+ * (adaptseg:94-100 followed by adaptseg:85): in_res = the previous block's input x, and A -- the new block input, which the
+ * next residual needs -- is also written to act_out (bf16 [B*H*W][Cin]).
+ * in_scale / in_shift: fp32 [Cin], or [B][Cin] with nsamples_affine = B (per-sample statistics, see diga_bn_finalize). */
+int diga_conv_igemm_bf16_fused_in(const diga_conv_desc* desc, const void* raw_in, const float* in_scale,
+                                  const float* in_shift, const void* in_res, void* act_out, int nsamples_affine,
+                                  const void* wgt, void* out, float* stat_slab, const float* stat_shift,
+                                  void* stream);
 /* out == NULL with a stat_slab: statistics only, nothing is stored.  Together with the entry point below this
  * replaces "conv3 -> bn3 -> += residual -> relu" (adaptseg:93-100) by two passes over the same GEMM: pass 1 takes
  * the DAM statistics, diga_bn_finalize makes the affine, pass 2 recomputes the conv and writes

@@ -412,3 +412,42 @@ def test_conv_with_fused_dam_finalize_is_bit_identical(B, H, W, Cin, Cout, k3, d
         assert torch.equal(out1.view(torch.int16), out0.view(torch.int16)) and torch.equal(slab1, slab0), rep
         assert torch.equal(sc1, sc0) and torch.equal(sh1, sh0), (rep, float((sc1 - sc0).abs().max()))
         assert int(ticket.abs().sum()) == 0, rep
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k3,dil,res,per_sample,tile", [
+    (1, 33, 65, 64, 256, False, 1, False, 0, 0), (2, 23, 31, 128, 128, True, 2, False, 2, 21), (3, 20, 27, 256, 64, False, 1, True, 3, 23),
+    (2, 65, 129, 256, 1024, False, 1, False, 2, 77), (2, 65, 129, 1024, 256, False, 1, True, 2, 76), (1, 65, 129, 512, 128, False, 1, True, 0, 61),
+    (2, 40, 50, 256, 256, True, 2, False, 2, 28), (1, 19, 23, 64, 128, True, 4, False, 0, 64), (2, 31, 45, 512, 256, False, 1, True, 0, 27)])
+def test_conv_with_fused_input_apply_is_bit_identical(B, H, W, Cin, Cout, k3, dil, res, per_sample, tile):
+    """diga_conv_igemm_bf16_fused_in (DAM apply + ReLU [+ residual] on the operand path) == diga_bn_apply followed by
+    diga_conv_igemm_bf16: raw output and statistics slab bit for bit; in the residual form the activation written on the side
+    (the next block's input) equals diga_bn_apply's output bit for bit.  3x3 halos stay zero padding."""
+    g = torch.Generator().manual_seed(H * 3 + Cin + Cout + tile)
+    raw = bf16_round(torch.randn(B, Cin, H, W, generator=g) * 1.5)
+    resid = bf16_round(torch.randn(B, Cin, H, W, generator=g).relu())
+    ks = 3 if k3 else 1
+    wt = bf16_round(torch.randn(Cout, Cin, ks, ks, generator=g) * (2.0 / (Cin * ks * ks)) ** 0.5)
+    ns = per_sample if per_sample else 1
+    sc = (torch.rand(ns, Cin, generator=g) + 0.5).to(DEV)
+    sh = (torch.randn(ns, Cin, generator=g) * 0.3).to(DEV)
+    shift = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    d = conv_desc(B, H, W, Cin, Cout, k3=k3, dil=dil, tile=tile)
+    rin, rres, wp = to_nhwc_bf16(raw), to_nhwc_bf16(resid), pack_conv_weight(wt).to(DEV)
+    M = B * H * W
+    units = call("diga_conv_stat_units", d)
+    act = torch.zeros(M * Cin, dtype=torch.bfloat16, device=DEV)
+    call("diga_bn_apply", P(rin), P(sc), P(sh), P(rres) if res else None, None, None, P(act), M, Cin, 1, per_sample, stream())
+    d0 = conv_desc(B, H, W, Cin, Cout, k3=k3, dil=dil, tile=0)
+    out0 = torch.zeros(M * Cout, dtype=torch.bfloat16, device=DEV)
+    slab0 = torch.zeros(units * 2 * Cout, dtype=torch.float32, device=DEV)
+    call("diga_conv_igemm_bf16", d0, P(act), P(wp), P(out0), P(slab0), P(shift), stream())
+    out1 = torch.full((M * Cout,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    slab1 = torch.full((units * 2 * Cout,), float("nan"), dtype=torch.float32, device=DEV)
+    act1 = torch.full((M * Cin,), float("nan"), dtype=torch.bfloat16, device=DEV) if res else None
+    call("diga_conv_igemm_bf16_fused_in", d, P(rin), P(sc), P(sh), P(rres) if res else None, P(act1), per_sample, P(wp), P(out1), P(slab1),
+         P(shift), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out1.view(torch.int16), out0.view(torch.int16)), float((out1.float() - out0.float()).abs().max())
+    assert torch.equal(slab1, slab0)
+    if res:
+        assert torch.equal(act1.view(torch.int16), act.view(torch.int16))

@@ -53,7 +53,7 @@ def diga(synth_params_np):
                                         (2, 65, 129, True), (1, 129, 257, True)])
 def test_stage_isolated_whole_net(weights, synth_params_np, B, H, W, fuse):
     pt = O.to_torch(synth_params_np)
-    eng = Engine(weights, B, H, W, fuse_conv3=fuse)
+    eng = Engine(weights, B, H, W, fuse_conv3=fuse, fuse_apply=False)     # every stage materialised so that it can be tapped
     eng.taps = {}
     x, _ = synth.synth_frame(0, B, H, W)
     eng.forward_feat(torch.from_numpy(x).cuda())
@@ -107,6 +107,32 @@ def test_stage_isolated_whole_net(weights, synth_params_np, B, H, W, fuse):
     pm = lg.softmax(1).max(1)[0].numpy()
     safe = np.abs(pm - 0.9) > 1e-6
     assert np.array_equal(eng.labels[:eng.P].cpu().numpy().reshape(pm.shape)[safe], O.pseudo_labels(lg, 0.9).numpy()[safe])
+
+
+@pytest.mark.parametrize("B,H,W,stream,mode", [(1, 129, 257, False, "all"), (2, 65, 129, False, "all"), (3, 129, 257, True, "all"),
+                                               (1, 512, 1024, False, "all"), (2, 129, 257, True, "conv1"), (2, 65, 129, False, "conv1")])
+def test_fused_apply_is_bit_identical_to_unfused(weights, B, H, W, stream, mode):
+    """Engine(fuse_apply=True) -- bn1 / bn2 applied on the operand path of conv2 / conv3, "bn3 + residual + relu" on the operand
+    path of the next block's conv1 -- against Engine(fuse_apply=False), where diga_bn_apply materialises every activation:
+    every raw conv output, every block output, features, logits, pseudo labels and the SAM output are bit-identical."""
+    ea = Engine(weights, B, H, W, stream=stream, fuse_apply=mode, autotune=True)
+    eb = Engine(weights, B, H, W, stream=stream, fuse_apply=False)
+    ea.taps, eb.taps = {}, {}
+    xs, ys = zip(*[synth.synth_frame(70 + t, 1, H, W) for t in range(B)])
+    x, y = torch.from_numpy(np.concatenate(xs)).cuda(), torch.from_numpy(np.concatenate(ys)).cuda()
+    pa, pb = ea.forward_and_adapt(x, y, CFG), eb.forward_and_adapt(x, y, CFG)
+    torch.cuda.synchronize()
+    common = sorted(set(ea.taps) & set(eb.taps))
+    assert len(common) >= 33 * 4 + 2 and (mode == "conv1" or not any(k.endswith("act1") for k in ea.taps))
+    for k in common:
+        assert torch.equal(ea.taps[k][0].view(torch.int16), eb.taps[k][0].view(torch.int16)), k
+    assert torch.equal(ea.feat.view(torch.int16), eb.feat.view(torch.int16)) and torch.equal(ea.logits, eb.logits)
+    assert torch.equal(ea.labels, eb.labels) and torch.equal(torch.nan_to_num(pa, nan=-1.0), torch.nan_to_num(pb, nan=-1.0))
+    # second pass with the autotuned tiles of the fused kernels (the first pass timed the candidates): still identical
+    pa2 = ea.forward_and_adapt(x, y, CFG)
+    pb2 = eb.forward_and_adapt(x, y, CFG)
+    torch.cuda.synchronize()
+    assert torch.equal(ea.feat.view(torch.int16), eb.feat.view(torch.int16)) and torch.equal(torch.nan_to_num(pa2, nan=-1.0), torch.nan_to_num(pb2, nan=-1.0))
 
 
 def _floor():
