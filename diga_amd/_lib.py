@@ -66,6 +66,7 @@ SIGNATURES = {
     "diga_instance_pool_work_bytes": (_i64, [_i, _i64, _i, _i, _i]),
     "diga_instance_pool": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "diga_upsample_argmax_hist": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "diga_argmax_hist": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "diga_upsample_argmax_hist_frames": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "diga_preprocess_image": (_i, [_vp, _i, _vp, _i, _i, _i, _d, _d, _d, _i, _vp]),
     "diga_map_labels": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _vp]),

@@ -179,7 +179,10 @@ __global__ __launch_bounds__(256) void proto_pool_kernel(const FT* __restrict__ 
   if (beg >= n) return;
   const int end = min(beg + CS, n);
   const int32_t* list = idx + ((size_t)s * C + c) * P;
-  float* dst = partial + (((size_t)s * C + c) * JC + j) * CH;
+  // chunks are laid out compactly per set: class c's chunks follow those of the classes before it (at most JC + C per set)
+  int off = 0;
+  for (int k = 0; k < c; ++k) off += (counts[s * C + k] + CS - 1) / CS;
+  float* dst = partial + ((size_t)s * (JC + C) + off + j) * CH;
   for (int ch0 = threadIdx.x * 8; ch0 < CH; ch0 += 2048) {
     float acc[8];
 #pragma unroll
@@ -213,8 +216,11 @@ __global__ void proto_reduce_kernel(const float* __restrict__ partial, const int
   if (ch >= CH) return;
   const int n = counts[sc];
   const int nj = (n + CS - 1) / CS;
+  const int s = sc / C, c = sc - s * C;
+  int off = 0;
+  for (int k = 0; k < c; ++k) off += (counts[s * C + k] + CS - 1) / CS;
   float v = 0.f;
-  for (int j = 0; j < nj; ++j) v += partial[((size_t)sc * JC + j) * CH + ch];
+  for (int j = 0; j < nj; ++j) v += partial[((size_t)s * (JC + C) + off + j) * CH + ch];
   sums[(size_t)sc * CH + ch] = v;
 }
 
@@ -550,12 +556,13 @@ struct PoolPlan {
 PoolPlan pool_plan(int nsets, int64_t P, int C, int CH) {      // nsets = label sets in the call (frames x sets per frame)
   PoolPlan pp;
   // chunk = list positions one block sums: ~P/256 so that the dominant classes alone spread over the whole chip
-  // (a chunk is a latency-bound chain of row reads; the partial buffer costs nsets*C*JC*CH floats)
+  // (a chunk is a latency-bound chain of row reads; the partial buffer holds a set's chunks compactly, class after class:
+  // at most JC + C chunks per set, i.e. nsets*(JC + C)*CH floats)
   pp.CS = (int)((P + 255) / 256);
   if (pp.CS < 32) pp.CS = 32;
   pp.JC = (int)((P + pp.CS - 1) / pp.CS);
   pp.idx_bytes = (((int64_t)nsets * C * P * 4) + 255) / 256 * 256;
-  pp.partial_bytes = (int64_t)nsets * C * pp.JC * CH * 4;
+  pp.partial_bytes = (int64_t)nsets * (pp.JC + C) * CH * 4;
   return pp;
 }
 }  // namespace

@@ -21,7 +21,10 @@ __device__ __forceinline__ void src_index(int dst, int in, int out, int& i0, int
   l0 = 1.f - l1;
 }
 
-template <typename T>
+// PLAIN: no interpolation at all (h == H, w == W): the metric called on full-resolution predictions, preds.argmax(1)
+// (ttda:178-179).  The bilinear form with equal sizes would multiply the +1 neighbour by weight 0, and 0 * NaN = NaN would
+// spread the 0/0 pixels of ttda:1733 to their left / upper neighbours -- which nn.Upsample does too, but argmax alone does not.
+template <typename T, bool PLAIN = false>
 __global__ __launch_bounds__(256) void upsample_argmax_hist_kernel(const float* __restrict__ probs, const T* __restrict__ target,
                                                                    uint8_t* __restrict__ pred, unsigned long long* __restrict__ hist,
                                                                    float* __restrict__ probs_up, int B, int C, int h, int w, int H,
@@ -34,14 +37,20 @@ __global__ __launch_bounds__(256) void upsample_argmax_hist_kernel(const float* 
     const int ox = (int)(i % W), oy = (int)((i / W) % H), b = (int)(i / ((int64_t)W * H));
     int y0, y1, x0, x1;
     float ly0, ly1, lx0, lx1;
-    src_index(oy, h, H, y0, y1, ly0, ly1);
-    src_index(ox, w, W, x0, x1, lx0, lx1);
+    if constexpr (!PLAIN) {
+      src_index(oy, h, H, y0, y1, ly0, ly1);
+      src_index(ox, w, W, x0, x1, lx0, lx1);
+    }
     const float* pb = probs + (size_t)b * C * h * w;
     float best = 0.f;
     int am = 0;
     for (int c = 0; c < C; ++c) {
       const float* pc = pb + (size_t)c * h * w;
-      const float v = ly0 * (lx0 * pc[y0 * w + x0] + lx1 * pc[y0 * w + x1]) + ly1 * (lx0 * pc[y1 * w + x0] + lx1 * pc[y1 * w + x1]);
+      float v;
+      if constexpr (PLAIN)
+        v = pc[oy * w + ox];
+      else
+        v = ly0 * (lx0 * pc[y0 * w + x0] + lx1 * pc[y0 * w + x1]) + ly1 * (lx0 * pc[y1 * w + x0] + lx1 * pc[y1 * w + x1]);
       if (probs_up) probs_up[(((size_t)b * C + c) * H + oy) * W + ox] = v;
       const bool better = c == 0 || (v > best) || (v != v && best == best);
       if (better) {
@@ -72,13 +81,19 @@ extern "C" int diga_version(void) { return 100; }
 
 namespace {
 int upsample_argmax_hist(const float* probs, const void* target, int target_is_i64, uint8_t* pred, int64_t* hist, float* probs_up, int B,
-                         int C, int h, int w, int H, int W, int hist_scale, void* stream) {
+                         int C, int h, int w, int H, int W, int hist_scale, void* stream, bool plain = false) {
   DIGA_CHECK_ARG(probs && target && hist, "diga_upsample_argmax_hist: NULL pointer");
   DIGA_CHECK_ARG(B > 0 && C > 0 && C <= DIGA_NUM_CLASSES_MAX && h > 0 && w > 0 && H > 0 && W > 0, "diga_upsample_argmax_hist: bad sizes");
   const int64_t total = (int64_t)B * H * W;
   const int cap = 2048 * (B < 4 ? 1 : 4);
   const int grid = total / 256 < cap ? cdiv(total, 256) : cap;
-  if (target_is_i64)
+  if (plain && target_is_i64)
+    hipLaunchKernelGGL((upsample_argmax_hist_kernel<int64_t, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, probs,
+                       (const int64_t*)target, pred, (unsigned long long*)hist, probs_up, B, C, h, w, H, W, hist_scale);
+  else if (plain)
+    hipLaunchKernelGGL((upsample_argmax_hist_kernel<int32_t, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, probs,
+                       (const int32_t*)target, pred, (unsigned long long*)hist, probs_up, B, C, h, w, H, W, hist_scale);
+  else if (target_is_i64)
     hipLaunchKernelGGL(upsample_argmax_hist_kernel<int64_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, probs,
                        (const int64_t*)target, pred, (unsigned long long*)hist, probs_up, B, C, h, w, H, W, hist_scale);
   else
@@ -97,4 +112,9 @@ extern "C" int diga_upsample_argmax_hist(const float* probs, const void* target,
 extern "C" int diga_upsample_argmax_hist_frames(const float* probs, const void* target, int target_is_i64, uint8_t* pred, int64_t* hist,
                                                 float* probs_up, int nframes, int C, int h, int w, int H, int W, void* stream) {
   return upsample_argmax_hist(probs, target, target_is_i64, pred, hist, probs_up, nframes, C, h, w, H, W, 1, stream);
+}
+
+extern "C" int diga_argmax_hist(const float* probs, const void* target, int target_is_i64, uint8_t* pred, int64_t* hist, int B, int C,
+                                int H, int W, void* stream) {
+  return upsample_argmax_hist(probs, target, target_is_i64, pred, hist, nullptr, B, C, H, W, H, W, B, stream, true);
 }

@@ -266,6 +266,7 @@ class Engine:
         self.feat = None          # bf16 NHWC view of the layer4 output, set by forward_feat
         self.conv_flops = 0       # 2*MAC of the executed convs (filled by the first forward_feat)
         self.conv_events = None   # optional list: (name, flops, start_event, end_event) per igemm launch (bench.py)
+        self.aux_events = None    # optional list: (kernel, algorithmic bytes, start_event, end_event) per HBM-bound launch (bench.py)
         self.taps = None          # optional dict: name -> (tensor, shape) of intermediate activations (tests)
 
     # ------------------------------------------------------------------ helpers
@@ -319,8 +320,10 @@ class Engine:
         return sc, sh
 
     def _apply(self, raw, sc, sh, res, rsc, rsh, out, M, Cc):
+        ev = self._aux_start()
         call("diga_bn_apply", _p(raw), _p(sc), _p(sh), _p(res), _p(rsc), _p(rsh), _p(out), M, Cc, 1,
              self.B if self.stream else 0, _stream())
+        self._aux_end(ev, "bn_apply", M * Cc * 2 * (2 if res is None else 3))     # read raw (+ residual), write the activation
 
     def _conv_bn(self, name, x, out, Hin, Win, Cin, Ho, Wo, Cout, stride, dil, k3, bn: BNP, fused_in=None):
         """One trunk conv + its DAM finalize -> (scale, shift) of the BN layer that follows it."""
@@ -382,7 +385,7 @@ class Engine:
             d.tile = self.tile_cache.get(key, 0)
         ev = self._ev_start()
         launch()
-        self._ev_end(ev, name + (":apply" if mode == "apply" else ""), flops)
+        self._ev_end(ev, name + (":apply" if mode == "apply" else ":fused_residual_in" if mode == "fin2" else ""), flops)
         self.conv_flops += flops
         return (Ho * Wo + 31) // 32          # statistics units per sample
 
@@ -418,6 +421,19 @@ class Engine:
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
+
+    def _aux_start(self):
+        if self.aux_events is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _aux_end(self, start, kernel, nbytes):
+        if start is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.aux_events.append((kernel, nbytes, start, e))
 
     def _ev_end(self, start, name, flops):
         if start is not None:
@@ -557,8 +573,10 @@ class Engine:
         nset = B if self.stream else 1
         # (stream mode: labels are [frame][pseudo | gt][hw], features [frame][hw][CH], sums [frame][2][C][CH] -- one set of
         # launches pools every frame, each bit-identical to its own call)
+        ev = self._aux_start()
         call("diga_proto_pool_frames", _p(self.feat), _p(self.labels), nset, 2, Ps, Cn, FEAT_CH, _p(self.pool_work), _p(self.pool_sums),
              _p(self.pool_counts), _stream())
+        self._aux_end(ev, "proto_pool", nset * Ps * (FEAT_CH * 2 + 2 * 4))      # one feature read serves both label sets
         if self.exchange:
             self._all_reduce(self.pool_sums)
             self._all_reduce(self.pool_counts)

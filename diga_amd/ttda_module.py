@@ -103,8 +103,7 @@ class SegmentationMetric(nn.Module):
             probs = preds.to(dev, torch.float32).contiguous()
         assert probs.shape[-2:] == tgt.shape[-2:]
         hist = torch.zeros(Cn * Cn, dtype=torch.int64, device=dev)
-        call("diga_upsample_argmax_hist", _p(probs), _p(tgt), int(tgt.dtype == torch.int64), None, _p(hist), None, B, Cn, H, W, H, W,
-             _stream())
+        call("diga_argmax_hist", _p(probs), _p(tgt), int(tgt.dtype == torch.int64), None, _p(hist), B, Cn, H, W, _stream())
         self.add_counts(hist.reshape(Cn, Cn))
 
     def forward(self, preds, target):

@@ -307,6 +307,10 @@ int diga_instance_pool(const void* feat, const int32_t* labels, int64_t label_sa
 int diga_upsample_argmax_hist(const float* probs, const void* target, int target_is_i64, uint8_t* pred,
                               int64_t* hist, float* probs_up, int B, int C, int h, int w, int H, int W,
                               void* stream);
+/* SegmentationMetric.update called on full-resolution probabilities (ttda:178-179, 168-173): preds.argmax(1) + confusion counts
+ * (x B), no interpolation -- a NaN pixel (the 0/0 branch, ttda:1733) stays one pixel. */
+int diga_argmax_hist(const float* probs, const void* target, int target_is_i64, uint8_t* pred, int64_t* hist,
+                     int B, int C, int H, int W, void* stream);
 /* nframes batch-1 metric updates (a stream of frames in flight) in one launch: the same as nframes calls with
  * B = 1 -- the counts are integers, so the sum does not depend on the order -- i.e. hist += bincount * 1 per frame. */
 int diga_upsample_argmax_hist_frames(const float* probs, const void* target, int target_is_i64, uint8_t* pred,

@@ -1,6 +1,8 @@
-"""Per-kernel roofline table from a rocprofv3 --kernel-trace of bench.py (profiles/collect.sh):
+"""Per-kernel roofline table from a rocprofv3 --kernel-trace of bench.py (profiles/collect_r2.sh):
 algorithmic bytes / FLOPs of one step (k frames in flight, 1024x512) divided by the kernel family's time per step.
-    python profiles/kernel_roofline.py gpurun_out/prof_r1d/trace/t_kernel_trace.csv 7 > profiles/r1d_kernel_roofline.md
+    python profiles/kernel_roofline.py gpurun_out/prof_r2/trace/t_kernel_trace.csv 15 profiles/r2_steady_state_kernels.csv > profiles/r2_kernel_roofline.md
+The optional third argument receives the steady-state per-kernel totals (calls and microseconds per step) as CSV, so that the
+table can be re-derived from tracked files.
 Only steady-state steps are counted (the first 8 stem launches = eager warm-up, tile autotune and graph warm-up are skipped);
 the number of steps is the stem kernel's remaining call count (one launch per step)."""
 import csv
@@ -20,8 +22,14 @@ for r in rows_all:
         continue
     n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
     key = n.split("(")[0]
+    for plain in ("stem_kernel", "proto_pool_kernel", "proto_dist_kernel"):      # templated on the storage type since round 2
+        if key.startswith(plain + "<"):
+            key = plain
     if key.startswith("conv_igemm_kernel"):
-        key = "conv_igemm_kernel"
+        # template arguments: <BM, BN, WM, WN, S, BK, ILV, EPI, AMODE>; AMODE 2 = "bn3 + residual + relu" of the previous block on
+        # the operand path (diga_conv_igemm_bf16_fused_in), a bandwidth-bound launch by construction
+        args = [a.strip() for a in n[n.index("<") + 1:n.rindex(">")].split(",")] if "<" in n else []
+        key = "conv_igemm_kernel[fused residual input]" if len(args) >= 9 and args[8] == "2" else "conv_igemm_kernel"
     dur[key] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
     calls[key] += 1
 steps = calls["stem_kernel"]
@@ -46,8 +54,15 @@ def add(name, kind, amount, peak, unit, note):
     rows.append((name, calls[name] // steps, t * 1e6, kind, ach, unit, ach / peak, note))
 
 
-add("conv_igemm_kernel", "mfma", 733.1e9, MFMA, "TFLOP/s", "104 trunk convs + head GEMM; FLOPs as SURVEY 8d")
-apply1 = sum((nb - 1) * px * 4 * pl * 2 * 3 for nb, pl, px in L)
+fused = "conv_igemm_kernel[fused residual input]" in dur
+fz_flops = sum((nb - 2) * 2.0 * px * 4 * pl * pl for nb, pl, px in L) if fused else 0.0       # conv1 of blocks 2..nb-1
+fz_bytes = sum((nb - 2) * px * (4 * pl * 2 * 3 + pl * 2) for nb, pl, px in L)
+add("conv_igemm_kernel", "mfma", 733.1e9 - fz_flops, MFMA, "TFLOP/s",
+    ("79 trunk convs + head GEMM (the 25 fused-input conv1 launches are the next row)" if fused else "104 trunk convs + head GEMM") + "; FLOPs as SURVEY 8d")
+if fused:
+    add("conv_igemm_kernel[fused residual input]", "hbm", fz_bytes, HBM, "GB/s",
+        f"conv1 + the previous block's bn3/residual/relu: read raw3 + x, write x' + raw1; also {fz_flops / 1e9:.1f} GFLOP per frame")
+apply1 = sum((1 if fused else nb - 1) * px * 4 * pl * 2 * 3 for nb, pl, px in L)
 apply2 = sum(px * 4 * pl * 2 * 3 for nb, pl, px in L)
 apply0 = sum(nb * px * pl * 2 * 2 * 2 for nb, pl, px in L)
 add("bn_apply_kernel<1>", "hbm", apply1, HBM, "GB/s", "read raw + residual, write block output (bf16)")
@@ -66,5 +81,10 @@ print("| kernel | launches/step | us/step | bound | achieved | frac of nominal p
 print("|---|---|---|---|---|---|---|")
 for name, c, us, kind, ach, unit, frac, note in rows:
     print(f"| `{name}` | {c} | {us:.0f} | {kind} | {ach:.0f} {unit} | {frac:.3f} | {note} |")
+if len(sys.argv) > 3:
+    with open(sys.argv[3], "w") as f:
+        f.write("kernel,calls_per_step,us_per_step\n")
+        for name in sorted(dur, key=lambda n_: -dur[n_]):
+            f.write(f"\"{name}\",{calls[name] / steps:.2f},{dur[name] / steps * 1e6:.1f}\n")
 tot = sum(dur.values()) / steps
 print(f"\nAll kernels: {tot * 1e3:.2f} ms of GPU time per step; nominal peaks: HBM {HBM:.0f} GB/s, bf16 MFMA {MFMA:.0f} TFLOP/s, fp32 vector {VALU:.1f} TFLOP/s.")

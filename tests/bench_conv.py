@@ -27,6 +27,7 @@ SHAPES = {
 }
 ALL_TILES = [1, 11, 21, 2, 12, 22, 3, 13, 23, 4, 14, 24, 16, 26, 17, 27, 28, 31, 32, 33, 34, 36, 37, 38, 46, 47, 48, 56,
              57, 58, 61, 64, 66, 67]
+MANIFEST = []        # launch order, for aligning rocprofv3 --pmc rows (profiles/pmc_conv.py)
 TILE_MN = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (64, 128), 5: (128, 32), 6: (256, 128), 7: (128, 256), 8: (256, 256)}
 
 
@@ -59,6 +60,7 @@ def run(name, tiles, reps, B=1):
         fl = 2.0 * M * Cout * Cin * taps
         res.append((tile, us, fl / us / 1e6, B * -(-(d.Ho * d.Wo) // bm) * (Cout // bn)))
     best = min(res, key=lambda r: r[1])
+    MANIFEST.append(dict(shape=name, B=B, launches=[dict(tile=t, n=3 + reps, us=round(us, 2), tflops=round(tf, 1), blocks=nb) for t, us, tf, nb in res]))
     print(f"{name:7s} M={B * d.Ho * d.Wo:6d} K={taps * Cin:5d} N={Cout:5d} {fl / 1e9:6.2f} GF | " +
           " ".join(f"t{t}:{us:6.1f}us/{tf:4.0f}TF/{nb}b" for t, us, tf, nb in res) + f" | best t{best[0]} {best[1]:.1f}us {best[2]:.0f}TF", flush=True)
 
@@ -69,9 +71,14 @@ if __name__ == "__main__":
     ap.add_argument("--tiles", default="")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--manifest", default="", help="write the launch order (shape, tile, launches) to this JSON file")
     a = ap.parse_args()
     tiles = [int(t) for t in a.tiles.split(",")] if a.tiles else ALL_TILES
     for n in SHAPES:
         if a.shapes and not any(n.startswith(s) for s in a.shapes.split(",")):
             continue
         run(n, tiles, a.reps, a.batch)
+    if a.manifest:
+        import json
+        with open(a.manifest, "w") as f:
+            json.dump(MANIFEST, f)

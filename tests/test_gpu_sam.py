@@ -288,3 +288,25 @@ def test_frames_in_flight_entry_points_equal_per_frame_calls(gold_sam):
                 assert np.array_equal(a[2][t].cpu().numpy(), g[f"mpl1_{t}_rflag"]), t
                 assert rel_err(a[1][t].cpu(), g[f"mpl1_{t}_run"]) < 1e-5, t
                 nan_close(a[0][t:t + 1].cpu(), g[f"mpl1_{t}_fused"], 1e-4)
+
+
+def test_metric_update_on_full_resolution_probs_with_nan_pixels():
+    """SegmentationMetric.update(preds, target) as the reference calls it (ttda:158-173): a plain arg-max per pixel.  A NaN pixel
+    (the 0/0 branch of ttda:1733) must stay ONE pixel: its left / upper neighbours keep their own class (the bilinear
+    kernel with equal sizes multiplied the +1 neighbour by weight 0, and 0 * NaN = NaN moved them to class 0)."""
+    from diga_amd import ttda_module as TM
+    g = torch.Generator().manual_seed(5)
+    probs = torch.rand(2, NC, 13, 17, generator=g) + 0.01
+    probs[:, 0] = 0.0                                    # class 0 never wins on its own
+    probs[0, :, 4, 5] = float("nan")
+    probs[1, :, 12, 16] = float("nan")
+    tgt = torch.randint(0, NC, (2, 13, 17), generator=g)
+    tgt[0, 0, :3] = 255
+    met = TM.SegmentationMetric(NC)
+    met.update(probs, tgt)
+    torch.cuda.synchronize()
+    pred = probs.argmax(1)                               # the reference's own rule: NaN -> its first NaN index = class 0
+    assert int(pred[0, 4, 5]) == 0 and int(pred[0, 4, 4]) != 0 and int(pred[0, 3, 5]) != 0
+    keep = (tgt >= 0) & (tgt < NC)
+    want = torch.bincount(NC * tgt[keep] + pred[keep], minlength=NC * NC).reshape(NC, NC) * 2
+    assert torch.equal(met.hist.cpu().long(), want)
