@@ -175,7 +175,7 @@ def run_config(args, world, rank, dev, group, weights, fif, steps, warmup, nwin=
     from diga_amd.engine import Engine
     from diga_amd.pipeline import StreamWindows
     H, W = args.height, args.width
-    kw = dict(bn_lambda=CFG["bn_lambda"], autotune=not args.no_autotune, force_exchange=args.rehearse_exchange)
+    kw = dict(bn_lambda=CFG["bn_lambda"], autotune=not args.no_autotune, force_exchange=args.rehearse_exchange, oneshot=args.oneshot)
     if nwin > 1:
         groups = None
         if group is not None:         # one process group (communicator) per window: see StreamWindows
@@ -202,7 +202,9 @@ def run_config(args, world, rank, dev, group, weights, fif, steps, warmup, nwin=
         eng.forward_and_adapt(x, y, CFG)
         eng.tail(y)
 
-    use_graph = (world == 1) and not args.no_graph and not args.rehearse_exchange
+    # the exchanges of the one-shot transport are ordinary kernel launches, so the sharded step can be replayed from a HIP graph
+    # too; with torch.distributed (RCCL) collectives between the kernels the N > 1 step is launched eagerly
+    use_graph = (world == 1 or args.oneshot) and not args.no_graph and not (args.rehearse_exchange and not args.oneshot)
     step_eager(0)
     step_eager(1)
     torch.cuda.synchronize()
@@ -272,6 +274,10 @@ def main():
                     help="N=1 only: run the N>1 code path (eager launches, one window, per-layer reduce_slab + RCCL all-reduce + "
                          "finalize_sums, prototype exchange) through a single-rank nccl group: what the sharded step costs before any "
                          "cross-GPU latency (not a bench line)")
+    ap.add_argument("--oneshot", action="store_true", default=bool(os.environ.get("DIGA_BENCH_ONESHOT")),
+                    help="N > 1 (or --rehearse-exchange): exchange BN / prototype sums with the one-launch direct-peer-write all-reduce "
+                         "(diga_amd/xgmi.py) instead of torch.distributed, and replay the step from a HIP graph.  Opt-in: tested with two "
+                         "ranks on one GPU only")
     ap.add_argument("--dump", default=None, help="write the per-conv timing table to this JSON file")
     args = ap.parse_args()
 
@@ -326,7 +332,7 @@ def main():
                                 + (f"; {nwin} window(s) of {fif} consecutive global batches in flight per step (one exchange per BN layer for all "
                                    "batches of a window; each window on its own HIP stream and RCCL communicator)" if fif * nwin > 1 else "")),
                    "resolution": f"{W}x{H}", "feature_grid": f"{eng.wd}x{eng.h}", "weights": "seeded synthetic init (diga_amd/synth.py)",
-                   "launch": "hipGraph replay" if use_graph else "eager", "backend": backend if world > 1 else ("nccl, single-rank rehearsal of the exchange path" if args.rehearse_exchange else None), "conv_tiles": "autotuned per shape" if eng.autotune else "fixed rule",
+                   "launch": "hipGraph replay" if use_graph else "eager", "backend": (backend + (" + one-shot peer-write all-reduce" if args.oneshot else "")) if world > 1 else ("nccl, single-rank rehearsal of the exchange path" if args.rehearse_exchange else None), "conv_tiles": "autotuned per shape" if eng.autotune else "fixed rule",
                    "includes": "net + SAM + fusion + upsample/argmax/confusion tail",
                    "frames_per_step": fif * nwin, "windows": nwin, "conv_gflop_per_frame": round(eng.conv_flops / fif / 1e9, 3)},
     }

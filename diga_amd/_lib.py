@@ -68,6 +68,12 @@ SIGNATURES = {
     "diga_upsample_argmax_hist": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "diga_argmax_hist": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "diga_upsample_argmax_hist_frames": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "diga_xgmi_buffer_bytes": (_i64, [_i, _i64]),
+    "diga_xgmi_create": (_i, [_i, _i, _i64, C.POINTER(_vp), _vp]),
+    "diga_xgmi_connect": (_i, [_vp, _vp]),
+    "diga_xgmi_destroy": (_i, [_vp]),
+    "diga_xgmi_allreduce": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "diga_xgmi_check": (_i, [_vp]),
     "diga_preprocess_image": (_i, [_vp, _i, _vp, _i, _i, _i, _d, _d, _d, _i, _vp]),
     "diga_map_labels": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _vp]),
     "diga_stem_conv7x7s2_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

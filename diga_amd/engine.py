@@ -146,7 +146,7 @@ class Engine:
     def __init__(self, weights: NetWeights, B: int, H: int, W: int, bn_lambda: float = 0.8, group=None,
                  confidence_threshold: float = 0.9, stream: bool = False, conv_tile: int = 0,
                  autotune: bool = False, fuse_conv3: bool = False, force_exchange: bool = False, fold_finalize: bool = False,
-                 fuse_apply="auto"):
+                 fuse_apply="auto", oneshot: bool = False):
         """stream=False: x is ONE batch of B samples -> the reference's batch semantics (half_first DAM statistics over
         the batch, prototypes pooled over the batch).  stream=True: x holds B CONSECUTIVE batch-1 frames of a stream
         ("frames in flight"): the trunk runs once over all of them with per-sample DAM statistics (DAM carries no
@@ -198,6 +198,13 @@ class Engine:
         # the statistics / prototype exchange runs whenever there is more than one rank; force_exchange takes the same
         # code path with a single-rank group (how the RCCL calls are exercised on a one-GPU box, tests/test_gpu_dist.py)
         self.exchange = self.world > 1 or (bool(force_exchange) and group is not None)
+        # oneshot: the exchanges go through the one-launch direct-peer-write all-reduce (diga_amd/xgmi.py) instead
+        # of torch.distributed (RCCL): no host round trip per layer, capturable in a HIP graph.  Opt-in: it has been run with two
+        # ranks on one GPU only (tests/test_gpu_dist.py), never across xGMI.
+        self.oneshot = None
+        if oneshot and self.exchange:
+            from .xgmi import OneShotComm
+            self.oneshot = OneShotComm(group, max_elems=max(1 << 17, B * 4 * 2048, B * 2 * weights.num_classes * (FEAT_CH + 1)))
         # fold_finalize: where every sample is normalised with its own statistics (batch 1, or a stream's frames in flight) the
         # DAM finalize can run inside the conv launch (diga_conv_igemm_bf16_dam: the last tile of each (sample, N tile) group
         # reduces the slab) -- bit-identical scale / shift, 103 launches fewer per pass.  Measured (same-box A/B):
@@ -279,6 +286,9 @@ class Engine:
         """Sum over ranks, in place.  RCCL ("nccl") reduces the device tensor on the stream; with the gloo backend
         (single-GPU rehearsal of the protocol in tests) the tensor takes a host round trip."""
         import torch.distributed as dist
+        if self.oneshot is not None and self.oneshot.supports(t):
+            self.oneshot.all_reduce(t)
+            return
         if dist.get_backend(self.group) == "gloo":
             h = t.cpu()
             dist.all_reduce(h, group=self.group)

@@ -318,6 +318,27 @@ int diga_upsample_argmax_hist_frames(const float* probs, const void* target, int
                                      int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * One-shot all-reduce over direct peer writes (no counterpart in the reference, which has no distributed code).
+ * For the sharded path's small, latency-bound exchanges (per BN layer [2][2][C] fp64 sums, per step the prototype sums):
+ * every rank writes its contribution into a slot of every peer's buffer (hipIpc-mapped, one hop over the direct xGMI link),
+ * raises a flag, waits (bounded) for the peers' flags on its own buffer and sums the slots in rank order -- one launch,
+ * deterministic, identical bits on every rank, capturable in a HIP graph.
+ * Set-up (these three allocate / map memory; the exchange itself does not):
+ *   diga_xgmi_create   -> local buffer + its 64-byte hipIpc handle; exchange the handles of all ranks out of band
+ *   diga_xgmi_connect  -> handles: world x 64 bytes in rank order (the own entry is ignored)
+ *   diga_xgmi_destroy
+ * diga_xgmi_allreduce: in-place sum over ranks of `count` values at `data` (device, 8-byte aligned); dtype 0 = fp64,
+ *   1 = fp32, 2 = int32 (4-byte types: count even); count*size <= max_elems*8.  Every rank must issue the same sequence of
+ *   calls (same counts).  diga_xgmi_check (synchronises the device) reports a peer that never arrived.
+ * ------------------------------------------------------------------------------------------ */
+int64_t diga_xgmi_buffer_bytes(int world, int64_t max_elems);
+int diga_xgmi_create(int world, int rank, int64_t max_elems, void** comm_out, void* ipc_handle_out64);
+int diga_xgmi_connect(void* comm, const void* handles_world_x64);
+int diga_xgmi_destroy(void* comm);
+int diga_xgmi_allreduce(void* comm, void* data, int64_t count, int dtype, void* stream);
+int diga_xgmi_check(void* comm);
+
+/* ------------------------------------------------------------------------------------------
  * Input pipeline: the arithmetic the reference's datasets apply to a decoded frame.
  * ------------------------------------------------------------------------------------------ */
 /* BaseDataset.preprocess (src/datamodules/seg/base_dataset.py:45-52): img HWC RGB (uint8 or the

@@ -18,7 +18,7 @@ def _worker(rank, world, port, q, k):
     os.makedirs("gpurun_out", exist_ok=True)
     log = open(f"gpurun_out/dist_rank{rank}.log", "w")
     try:
-        (_worker_b8 if k == 8 else _worker_windows if k < 0 else _worker_stream if k > 1 else _worker_body)(rank, world, port, q, log, k)
+        (_worker_oneshot if k == 100 else _worker_b8 if k == 8 else _worker_windows if k < 0 else _worker_stream if k > 1 else _worker_body)(rank, world, port, q, log, k)
     except Exception:
         traceback.print_exc(file=log)
         log.flush()
@@ -72,6 +72,74 @@ def _worker_b8(rank, world, port, q, log, k):
                         run=eng.run_proto.cpu().numpy(), rflag=eng.run_flag.cpu().numpy()))
     dist.barrier()
     q.put((rank, out))
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+def _worker_oneshot(rank, world, port, q, log, k):
+    """The one-launch direct-peer-write all-reduce (csrc/xgmi.hip) between two processes that share cuda:0 (their buffers are
+    mapped into each other with hipIpc exactly as two GPUs' would be), then the sharded engine on top of it."""
+    import torch.distributed as dist
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    from diga_amd.xgmi import OneShotComm
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    comm = OneShotComm(dist.group.WORLD, max_elems=1 << 17)
+    print("communicator connected", file=log, flush=True)
+    ok = True
+    g = torch.Generator().manual_seed(123)          # the same stream on both ranks: each knows the other's contribution
+    for rep in range(40):                            # back to back: parities alternate, epochs advance per block
+        for dt, n in ((torch.float64, 4 * 64), (torch.float64, 4 * 2048), (torch.float32, 2 * 19 * 2048), (torch.int32, 38), (torch.float64, 100003)):
+            if dt == torch.int32:
+                parts = [torch.randint(0, 10000, (n,), generator=g, dtype=dt) for _ in range(world)]
+            else:
+                parts = [torch.randn(n, generator=g, dtype=dt) for _ in range(world)]
+            t = parts[rank].cuda()
+            comm.all_reduce(t)
+            want = parts[0].clone()
+            for p in parts[1:]:
+                want += p                            # rank order: bit-exact
+            good = torch.equal(t.cpu(), want)
+            if not good:
+                print("MISMATCH", rep, dt, n, float((t.cpu().double() - want.double()).abs().max()), file=log, flush=True)
+            ok = ok and good
+    comm.check()
+    print("raw all-reduces", "ok" if ok else "FAILED", file=log, flush=True)
+    # the sharded engine through the one-shot transport
+    w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
+    eng = Engine(w, 1, H, W, group=dist.group.WORLD, oneshot=True)
+    out = []
+    for t in range(NF):
+        x, y = synth.synth_frame(t, world, H, W)
+        probs = eng.forward_and_adapt(torch.from_numpy(x[rank:rank + 1]).cuda(), torch.from_numpy(y[rank:rank + 1]).cuda(), CFG)
+        torch.cuda.synchronize()
+        out.append(dict(probs=probs.cpu().numpy(), logits=eng.logits.cpu().numpy(), scale=eng.scale.cpu().numpy(),
+                        run=eng.run_proto.cpu().numpy(), rflag=eng.run_flag.cpu().numpy()))
+    # and one step replayed from a HIP graph (the exchange is an ordinary kernel launch: no host round trip)
+    x, y = synth.synth_frame(NF, world, H, W)
+    xd, yd = torch.from_numpy(x[rank:rank + 1]).cuda(), torch.from_numpy(y[rank:rank + 1]).cuda()
+    state = [t_.clone() for t_ in (eng.run_proto, eng.run_flag, eng.state_flag)]
+    eager = eng.forward_and_adapt(xd, yd, CFG).clone()
+    torch.cuda.synchronize()
+    for dst, src in zip((eng.run_proto, eng.run_flag, eng.state_flag), state):
+        dst.copy_(src)
+    dist.barrier()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        eng.forward_and_adapt(xd, yd, CFG)
+    for dst, src in zip((eng.run_proto, eng.run_flag, eng.state_flag), state):
+        dst.copy_(src)
+    dist.barrier()
+    gr.replay()
+    torch.cuda.synchronize()
+    graph_ok = bool(torch.equal(torch.nan_to_num(eng.probs, nan=-1.0), torch.nan_to_num(eager, nan=-1.0)))
+    eng.oneshot.check()
+    print("graph replay", "identical" if graph_ok else "DIFFERENT", file=log, flush=True)
+    dist.barrier()
+    q.put((rank, dict(ok=ok and graph_ok, frames=out)))
     try:
         dist.destroy_process_group()
     except Exception:
@@ -247,6 +315,30 @@ def test_two_ranks_reproduce_batch8_and_the_reference_fixture():
         both = np.concatenate([res[0][t]["logits"], res[1][t]["logits"]])
         rl = g[f"b8s_{t}_logits"]
         assert np.abs(both - rl).max() / (rl.max() - rl.min()) < 0.03
+
+
+def test_two_ranks_oneshot_allreduce_and_engine():
+    """the one-launch all-reduce over direct peer writes, two processes on one GPU (hipIpc-mapped buffers): 200 raw
+    all-reduces of fp64 / fp32 / int32 payloads back to back are bit-exact sums in rank order; the sharded engine on top of it
+    reproduces the single-process batch-2 engine (scale / shift of all 104 layers and logits bit-identical); a step captured in
+    a HIP graph replays to the same result."""
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    res = _run_ranks(100)
+    assert res[0]["ok"] and res[1]["ok"], "see gpurun_out/dist_rank*.log"
+    w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
+    eng = Engine(w, 2, H, W)
+    for t in range(NF):
+        x, y = synth.synth_frame(t, 2, H, W)
+        probs = eng.forward_and_adapt(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), CFG)
+        torch.cuda.synchronize()
+        for r in range(2):
+            got = res[r]["frames"][t]
+            assert np.array_equal(got["scale"], eng.scale.cpu().numpy()), (t, r)
+            assert np.array_equal(got["logits"][0], eng.logits.cpu().numpy()[r]), (t, r)
+            assert np.nanmax(np.abs(got["probs"][0] - probs.cpu().numpy()[r])) < 1e-4
+            assert np.array_equal(got["rflag"], eng.run_flag.cpu().numpy())
+        assert np.array_equal(res[0]["frames"][t]["run"], res[1]["frames"][t]["run"])
 
 
 def _rccl_worker(port, q):
