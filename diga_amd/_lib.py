@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DIGA_HIP_LIB") or os.path.join(_HERE, "csrc", "libdiga_hip.so")   # override: A/B builds
+LIB_PATH = os.path.join(_HERE, "csrc", "libdiga_hip.so")
 
 MAX_TAPS = 18
 

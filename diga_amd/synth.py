@@ -10,7 +10,7 @@ activations and drives every frame into the all-NaN branch (SURVEY.md section 0 
 benchmark / parity weights are a build-defined init: He-scaled convs, BN affine drawn from narrow
 ranges and BN source statistics *calibrated* on synthetic frames and then perturbed (a stand-in for
 source-vs-target domain shift).  The calibrated statistics are committed as data
-(``tests/golden/synth_bn_stats_seed0.npz``, written by ``tests/golden/make_synth_bn_stats.py``).
+(``diga_amd/data/synth_bn_stats_seed0.npz``, written by ``tests/golden/make_synth_bn_stats.py``).
 """
 from __future__ import annotations
 
@@ -24,8 +24,7 @@ LAYERS = (3, 4, 23, 3)
 PLANES = (64, 128, 256, 512)
 HEAD_DILATIONS = (6, 12, 18, 24)
 
-_BN_STATS_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                              "tests", "golden", "synth_bn_stats_seed0.npz")
+_BN_STATS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "synth_bn_stats_seed0.npz")
 
 
 def _rng(seed: int, name: str) -> np.random.Generator:

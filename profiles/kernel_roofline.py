@@ -22,7 +22,7 @@ for r in rows_all:
         continue
     n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
     key = n.split("(")[0]
-    for plain in ("stem_kernel", "proto_pool_kernel", "proto_dist_kernel"):      # templated on the storage type since round 2
+    for plain in ("stem_kernel", "proto_pool_kernel", "proto_dist_kernel", "upsample_argmax_hist_kernel"):      # templated on the storage type since round 2
         if key.startswith(plain + "<"):
             key = plain
     if key.startswith("conv_igemm_kernel"):
@@ -74,7 +74,6 @@ add("stem_kernel", "valu", 2 * hw1 * 64 * 147, VALU, "TFLOP/s", "7x7 s2 conv, fp
 add("bn_relu_maxpool_kernel", "hbm", hw1 * 64 * 2 + hw2 * 64 * 2, HBM, "GB/s", "read stem output, write pooled")
 add("proto_pool_kernel", "hbm", hw3 * 2048 * 2, HBM, "GB/s", "one feature read serves both label sets")
 add("proto_dist_kernel", "valu", 3.0 * hw3 * 38 * 2048, VALU, "TFLOP/s", "sub + fma per (pixel, prototype, channel)")
-add("upsample_argmax_hist_kernel", "l2", 512 * 1024 * (19 * 4 * 4 + 8 + 1), HBM, "GB/s", "4 taps x 19 classes per output pixel (cache-resident), label read, pred write")
 add("head_tapsum_pl_kernel", "l2", hw3 * (18 * 19 * 4 + 19 * 4 + 4), HBM, "GB/s", "18 x 76-byte reads per pixel")
 print(f"# Per-kernel roofline, {k} frames in flight, 1024x512, {steps} steps in the trace (rocprofv3 --kernel-trace)\n")
 print("| kernel | launches/step | us/step | bound | achieved | frac of nominal peak | algorithmic work counted |")

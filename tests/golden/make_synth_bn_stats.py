@@ -3,7 +3,7 @@
 Runs the CPU oracle once over a full-resolution synthetic calibration frame; just before each of the
 104 BN layers runs, its running_mean / running_var are set to the statistics of its actual input,
 perturbed by a seeded factor (mean += N(0, 0.15 std), var *= U(0.8, 1.25)) that stands in for the
-source->target domain shift DAM is designed to absorb.  Output: tests/golden/synth_bn_stats_seed0.npz
+source->target domain shift DAM is designed to absorb.  Output: diga_amd/data/synth_bn_stats_seed0.npz
 (421 KB), loaded by diga_amd.synth.synth_params().
 
     python tests/golden/make_synth_bn_stats.py
@@ -41,7 +41,7 @@ def main(seed=0, H=512, W=1024):
     with torch.no_grad():
         feat, logits = O.net_forward_feat(p, torch.from_numpy(x), 0.8)
     O.BN_PRE_HOOK = None
-    out = os.path.join(ROOT, "tests", "golden", f"synth_bn_stats_seed{seed}.npz")
+    out = os.path.join(ROOT, "diga_amd", "data", f"synth_bn_stats_seed{seed}.npz")
     np.savez_compressed(out, **stats)
     prob = logits.softmax(1)
     pm, am = prob.max(1)
