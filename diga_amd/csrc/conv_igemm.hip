@@ -76,6 +76,16 @@ struct ConvKParams {
 // 16 zero bytes: the source of every out-of-image / out-of-range 16-byte chunk of the gather
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
 
+// Per-tile phase clock (profiles/experiments/tile_clock): compiled in with -DDIGA_TILE_CLOCK only, never in the product build.
+#ifdef DIGA_TILE_CLOCK
+__device__ unsigned long long g_tile_clock[16 * 16384];
+#define DIGA_TCLK(i) tclk[i] = wall_clock64()   /* kept in registers: a store inside the K loop would disturb its vmcnt counting */
+#else
+#define DIGA_TCLK(i) \
+  do {               \
+  } while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -87,14 +97,24 @@ __device__ __forceinline__ void wait_vmcnt() {
 // 5 = fp32 output + statistics (verification mode: nothing is rounded to bf16 between the accumulators and the next stage).
 enum { EPI_BF16_STATS = 0, EPI_F32 = 1, EPI_BF16 = 2, EPI_STATS_ONLY = 3, EPI_FUSED_APPLY = 4, EPI_F32_STATS = 5 };
 
-template <int BM, int BN, int WM, int WN, int S, int BK, bool ILV, int EPI, int AMODE = 0>
+// MF = the MFMA shape: 16 = v_mfma_f32_16x16x32_bf16 (the build default), 32 = v_mfma_f32_32x32x16_bf16 (-DDIGA_MF=32, kept
+// for A/B runs).  Same FLOPs per cycle, the same LDS bytes and -- measured, tests/test_gpu_kernels.py -- the same bits in the
+// fp32 accumulators; under load the chip holds a higher clock on the 16x16x32 form (MI355X_MICROARCH.md 'DVFS give-back'
+// item 7): same-box A/B at 15 frames, 256x256 tiles: l3.c2 171 -> 147 us, l4.c2 544 -> 477 us (1244 TFLOP/s).
+#ifndef DIGA_MF
+#define DIGA_MF 16
+#endif
+template <int BM, int BN, int WM, int WN, int S, int BK, bool ILV, int EPI, int AMODE = 0, int MF = DIGA_MF>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKParams p) {
   static_assert(AMODE == 0 || (S == 2 && !ILV && EPI == EPI_BF16_STATS), "the fused-input path: 2-deep ring, burst issue, trunk epilogue");
+  static_assert(MF == 32 || MF == 16, "MFMA shape");
   constexpr bool OUT_F32 = EPI == EPI_F32 || EPI == EPI_F32_STATS;
   constexpr bool STATS = EPI == EPI_BF16_STATS || EPI == EPI_STATS_ONLY || EPI == EPI_F32_STATS;
   constexpr int NW = WM * WN, NTHR = 64 * NW;        // 4 or 8 waves
   constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int MT = WTM / MF, NT = WTN / MF;      // MFMA tiles per wave
+  constexpr int AR = MF == 32 ? 16 : 4;            // accumulator registers per MFMA tile
+  using acc_t = std::conditional_t<MF == 32, f32x16, f32x4>;
   // K step = BK channels (64 or 32): LDS rows of ROWB bytes = CPRW 16-byte chunks; one 1-KiB LDS-DMA wave-instruction
   // covers RPI rows.  BK = 32 halves the stage, so twice as many stages (loads in flight) fit the same LDS.
   constexpr int ROWB = BK * 2, CPRW = BK / 8, RPI = 64 / CPRW;
@@ -107,9 +127,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // the ONLY LDS object (cdna guide 5, trap 4a)
 
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef DIGA_TILE_CLOCK
+  unsigned long long tclk[8];
+#endif
+  DIGA_TCLK(0);
+#ifdef DIGA_TILE_CLOCK
+  if (tid == 0 && blockIdx.x < 16384) {
+    g_tile_clock[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+    g_tile_clock[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+  }
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int l31 = lane & 31, hh = lane >> 5;
+  // lane -> (column of the MFMA tile, row group): 32x32x16: col = lane & 31, hh = lane >> 5; 16x16x32: col = lane & 15, fq = lane >> 4
+  const int l31 = lane & (MF - 1), hh = lane / MF;
+  // accumulator element r of MFMA tile (a, b): its row / column inside the wave's WTM x WTN tile
+  auto acc_row = [&](int a, int r) { return MF == 32 ? a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh : a * 16 + 4 * hh + r; };
+  auto acc_col = [&](int b) { return b * MF + l31; };
 
   // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
   // run of logical tile ids (N tiles of one M tile share the gathered A rows in that XCD's L2).
@@ -134,8 +168,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
   // applied on the SOURCE: slot s of row r holds channel chunk s ^ swz(r), swz(r) = (r>>1)&7 for 128-byte rows,
   // (r>>2)&3 for 64-byte rows: 16 consecutive rows then cover all 16 bank quads (cdna guide 5.4 rule 21).
   // Wave w owns row groups w, w+NW, ... (rows RPI*(w + NW*i) + l/CPRW); those rows are fixed for the whole K loop.
+  // (64-byte rows under 16x16x32 reads: a lane group of one ds_read_b128 takes rows 0-3 and 12-15 of chunk fq and rows 4-11
+  // of chunk fq + 1; XOR 3 on rows 8-15 puts its 16 lanes on the 16 bank quads)
+  auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : MF == 32 ? (row >> 2) & 3 : ((row >> 3) & 1) * 3; };
   const int lrow = RPI * wave + lane / CPRW;
-  const int cch = (lane % CPRW) ^ (BK == 64 ? (lrow >> 1) & 7 : (lrow >> 2) & 3);   // swz is i-invariant
+  const int cch = (lane % CPRW) ^ swz(lrow);                    // rows advance by multiples of 16 with i: swz is i-invariant
   // K steps [ks_begin, ks_end) of the launch's nterms * nk_plane: term = step / nk_plane picks the operand planes
   int is_term = ks_begin / p.nk_plane;
   int is_kin = ks_begin - is_term * p.nk_plane;                 // K step inside the term
@@ -275,15 +312,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     advance_next();
   };
 
-  f32x16 acc[MT][NT];
+  acc_t acc[MT][NT];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < AR; ++r) acc[a][b][r] = 0.f;
 
-  const int fr_swz = BK == 64 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
+  // fragment reads: lane (l31, hh) reads the 16-byte chunk (KCH * s + hh) of row l31 of each MFMA tile; the row's swizzle
+  // depends on l31 only (tile origins are multiples of 16 rows)
+  const int fr_swz = swz(l31);
   const int fa_row = (wm * WTM + l31) * ROWB, fb_row = A_BYTES + (wn * WTN + l31) * ROWB;
 
   // ---- K loop: S-deep LDS ring filled by LDS-DMA, one raw barrier per K step, counted vmcnt so that up to
@@ -292,6 +331,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
   for (int s = 0; s < D; ++s)
     if (s < nt) issue_next(s);
   int stage = 0, fill = D % S;
+  DIGA_TCLK(1);
+  DIGA_TCLK(2);
+#ifdef DIGA_TILE_CLOCK
+  const unsigned long long sclk0 = clock64();
+#endif
   for (int t = 0; t < nt; ++t) {
     // tile t must have landed: leave at most min(D-1, nt-1-t) younger tiles of THIS wave outstanding
     const int younger = min(D - 1, nt - 1 - t);
@@ -307,25 +351,35 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     if (!ILV && more) issue_next(fill);
     const unsigned char* bA = smem + stage * STAGE_BYTES + fa_row;
     const unsigned char* bB = smem + stage * STAGE_BYTES + fb_row;
-    constexpr int KS = BK / 16;
+    constexpr int KCH = 64 / MF;          // 16-byte chunks one MFMA consumes along K: 2 (K = 16) or 4 (K = 32)
+    constexpr int KS = BK / (8 * KCH);
     auto ksub = [&](auto s_c) {
       constexpr int s = decltype(s_c)::value;
-      const int coff = ((2 * s + hh) ^ fr_swz) << 4;
+      const int coff = ((KCH * s + hh) ^ fr_swz) << 4;
       bf16x8 fa[MT], fb[NT];
 #pragma unroll
-      for (int a = 0; a < MT; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(bA + a * 32 * ROWB + coff);
+      for (int a = 0; a < MT; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(bA + a * MF * ROWB + coff);
 #pragma unroll
-      for (int b = 0; b < NT; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(bB + b * 32 * ROWB + coff);
-      if (ILV && more)                  // this group's share of the next K step's loads, in the shadow of the MFMAs below
-        issue_pieces(fill, std::integral_constant<int, s * LPT / KS>{}, std::integral_constant<int, (s + 1) * LPT / KS>{});
+      for (int b = 0; b < NT; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(bB + b * MF * ROWB + coff);
+#ifdef DIGA_ILV_FRONT
+      constexpr int IG = KS / 2;        // experiment: the loads ride the first half of the step's MFMA groups only
+#else
+      constexpr int IG = KS;
+#endif
+      if (ILV && more && s < IG)        // this group's share of the next K step's loads, in the shadow of the MFMAs below
+        issue_pieces(fill, std::integral_constant<int, (s < IG ? s : 0) * LPT / IG>{}, std::integral_constant<int, ((s < IG ? s : 0) + 1) * LPT / IG>{});
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NT; ++b) {
+          if constexpr (MF == 32)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+          else
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
     };
     ksub(std::integral_constant<int, 0>{});
-    ksub(std::integral_constant<int, 1>{});
+    if constexpr (KS >= 2) ksub(std::integral_constant<int, 1>{});
     if constexpr (KS == 4) {
       ksub(std::integral_constant<int, 2>{});
       ksub(std::integral_constant<int, 3>{});
@@ -335,52 +389,64 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     fill = fill + 1 == S ? 0 : fill + 1;
   }
   __syncthreads();                      // all LDS reads done: the epilogue reuses the ring
+  DIGA_TCLK(3);
+#ifdef DIGA_TILE_CLOCK
+  const unsigned long long sclk1 = clock64();
+#endif
 
   // ------------------------------------------------------------------ epilogue
-  // accumulator element r of tile (a,b): row = wm*WTM + a*32 + (r&3) + 8*(r>>2) + 4*hh, col = wn*WTN + b*32 + l31
+  // accumulator element r of tile (a,b): row = wm*WTM + acc_row(a, r), col = wn*WTN + acc_col(b)
   if constexpr (STATS) {
-    // One statistics unit = the 32 rows of one MFMA tile row-block: lane (l31, hh) holds 16 of the 32 rows of
-    // column l31, the other half-wave holds the rest -> 16 adds + one cross-half shuffle, no LDS, and the unit's
-    // value does not depend on the tile shape.  Units that lie entirely in the sample's padding are skipped.
+    // One statistics unit = 32 consecutive rows of the sample x one channel, summed in ONE fixed tree whatever the tile
+    // shape and the MFMA shape, so that a unit's bits do not depend on which kernel produced it:
+    //   rows 4g .. 4g+3 (g = 0..7):  S_g = (d0 + d1) + (d2 + d3),  Q_g = fma(d1, d1, d0*d0) + fma(d3, d3, d2*d2),  d = x - shift[c]
+    //   unit = [(g0 + g4) + (g2 + g6)] + [(g1 + g5) + (g3 + g7)]
+    // Both accumulator layouts keep whole 4-row groups in one lane: 32x32x16 has groups hh, 2+hh, 4+hh, 6+hh (registers
+    // 4q .. 4q+3 = group 2q + hh), 16x16x32 has group fq of each of the unit's two 16-row tiles (fq and 4 + fq); the rest
+    // of the tree is one (32x32) or two (16x16) cross-lane adds.  Rows beyond the sample contribute d = 0.
+    constexpr int UT = 32 / MF;                           // MFMA tile rows per unit: 1 or 2
 #pragma unroll
-    for (int a = 0; a < MT; ++a) {
-      const int ubase = r0 + wm * WTM + a * 32;        // first row (inside the sample) of this unit: wave-uniform
+    for (int ua = 0; ua < MT / UT; ++ua) {
+      const int ubase = r0 + wm * WTM + ua * 32;          // first row (inside the sample) of this unit: wave-uniform
       if (ubase < p.hw) {
         const bool full = ubase + 32 <= p.hw;
         const size_t urow = ((size_t)n_img * p.units_per_sample + (ubase >> 5)) * 2;
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
-          const int c = n0 + wn * WTN + b * 32 + l31;
+          const int c = n0 + wn * WTN + acc_col(b);
           const float kshift = c < p.Cout ? p.shift[c] : 0.f;
-          float t1 = 0.f, t2 = 0.f;
-          if (full) {
-            // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two rows per instruction -- with a short K loop (conv3: K = 256)
-            // this epilogue is a third of a tile's time and the MFMA pipe idles through it.  Even rows and odd rows are
-            // summed separately and added at the end: a fixed order, the same for every tile shape.
-            f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
-            const f32x2 ks = {kshift, kshift};
+          // group sums of the 4 registers acc[a][b][4q .. 4q+3], whose first row inside the unit is `row0`
+          auto group = [&](int a, int q, int row0, float& sg, float& qg) {
+            float d[4];
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-              const f32x2 x = {acc[a][b][r], acc[a][b][r + 1]};
-              const f32x2 d = x - ks;
-              p1 += d;
-              p2 = __builtin_elementwise_fma(d, d, p2);
+            for (int i = 0; i < 4; ++i) {
+              d[i] = acc[a][b][4 * q + i] - kshift;
+              if (!full && ubase + row0 + i >= p.hw) d[i] = 0.f;
             }
-            t1 = p1[0] + p1[1];
-            t2 = p2[0] + p2[1];
+            sg = (d[0] + d[1]) + (d[2] + d[3]);
+            qg = fmaf(d[1], d[1], d[0] * d[0]) + fmaf(d[3], d[3], d[2] * d[2]);
+          };
+          float t1, t2;
+          if constexpr (MF == 32) {
+            float sg[4], qg[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) group(ua, q, 8 * q + 4 * hh, sg[q], qg[q]);
+            t1 = (sg[0] + sg[2]) + (sg[1] + sg[3]);       // (g_hh + g_4+hh) + (g_2+hh + g_6+hh)
+            t2 = (qg[0] + qg[2]) + (qg[1] + qg[3]);
+            t1 += __shfl_xor(t1, 32);
+            t2 += __shfl_xor(t2, 32);
           } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float d = acc[a][b][r] - kshift;
-              if (ubase + (r & 3) + 8 * (r >> 2) + 4 * hh < p.hw) {
-                t1 += d;
-                t2 = fmaf(d, d, t2);
-              }
-            }
+            float s0, q0, s1, q1;
+            group(2 * ua, 0, 4 * hh, s0, q0);             // group fq
+            group(2 * ua + 1, 0, 16 + 4 * hh, s1, q1);    // group 4 + fq
+            t1 = s0 + s1;
+            t2 = q0 + q1;
+            t1 += __shfl_xor(t1, 32);                     // + the pair of fq ^ 2
+            t2 += __shfl_xor(t2, 32);
+            t1 += __shfl_xor(t1, 16);                     // even groups + odd groups
+            t2 += __shfl_xor(t2, 16);
           }
-          t1 += __shfl_xor(t1, 32);
-          t2 += __shfl_xor(t2, 32);
-          if (c < p.Cout) {
+          if (c < p.Cout && hh < 2) {
             if (p.fin_ticket)      // read back inside this launch by another block, maybe on another XCD: write through
               __hip_atomic_store(&p.slab[(urow + hh) * p.Cout + c], hh ? t2 : t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else
@@ -391,21 +457,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     }
   }
 
+  DIGA_TCLK(4);
   if constexpr (OUT_F32) {
     float* out = reinterpret_cast<float*>(p.out) + (size_t)blockIdx.y * p.M * p.cout_pad;
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < NT; ++b) {
-        const int c = n0 + wn * WTN + b * 32 + l31;
+        const int c = n0 + wn * WTN + acc_col(b);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rem = r0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        for (int r = 0; r < AR; ++r) {
+          const int rem = r0 + wm * WTM + acc_row(a, r);
           if (rem < p.hw) out[(size_t)(m_base + rem) * p.cout_pad + c] = acc[a][b][r];
         }
       }
   } else if constexpr (EPI != EPI_STATS_ONLY) {
-    unsigned short* sC = reinterpret_cast<unsigned short*>(smem);   // [BM][BN] bf16
+    unsigned short* sC = reinterpret_cast<unsigned short*>(smem);   // [BM][SC_LD] bf16
+    // 16x16x32 accumulators put rows 4 apart on the four lane groups of one ds_write_b16: 16 bytes of row padding keep
+    // them two-way on the banks, as the 32x32x16 layout is
+    constexpr int SC_LD = MF == 16 ? BN + 8 : BN;
     constexpr int CPR = BN / 8;                       // 16-byte chunks per tile row
     if constexpr (EPI == EPI_FUSED_APPLY) {
       // the residual tile comes in first, with coalesced 16-byte loads (read for the last time: non-temporal)
@@ -418,7 +488,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
         u32x4 v = {0u, 0u, 0u, 0u};
         if (rem < p.hw && c < p.Cout)
           v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(res + (size_t)(m_base + rem) * p.Cout + c));
-        *reinterpret_cast<u32x4*>(sC + row * BN + cc * 8) = v;
+        *reinterpret_cast<u32x4*>(sC + row * SC_LD + cc * 8) = v;
       }
       __syncthreads();
     }
@@ -426,7 +496,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
     for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < NT; ++b) {
-        const int col = wn * WTN + b * 32 + l31;
+        const int col = wn * WTN + acc_col(b);
         float esc = 1.f, esh = 0.f;
         if constexpr (EPI == EPI_FUSED_APPLY) {
           const int c = n0 + col;
@@ -436,19 +506,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
           }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        for (int r = 0; r < AR; ++r) {
+          const int row = wm * WTM + acc_row(a, r);
           if constexpr (EPI == EPI_FUSED_APPLY) {
             // the arithmetic of bn_apply_kernel<1> on the unrounded accumulator: y = fma(x, scale, shift) + residual
-            float y = fmaf(acc[a][b][r], esc, esh) + bf16_bits_to_f32(sC[row * BN + col]);
+            float y = fmaf(acc[a][b][r], esc, esh) + bf16_bits_to_f32(sC[row * SC_LD + col]);
             if (p.ep_relu) y = fmaxf(y, 0.f);
-            sC[row * BN + col] = f32_to_bf16_bits(y);
+            sC[row * SC_LD + col] = f32_to_bf16_bits(y);
           } else {
-            sC[row * BN + col] = f32_to_bf16_bits(acc[a][b][r]);
+            sC[row * SC_LD + col] = f32_to_bf16_bits(acc[a][b][r]);
           }
         }
       }
     __syncthreads();
+    DIGA_TCLK(5);
     unsigned short* out = reinterpret_cast<unsigned short*>(p.out);
 #pragma unroll
     for (int i = 0; i < BM * CPR / NTHR; ++i) {
@@ -458,10 +529,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
       if (rem < p.hw && c < p.Cout)
         // the raw output is read exactly once, by bn_apply: a non-temporal store keeps it from displacing the A / B lines
         // the other tiles still need in L2 (+2.5 % whole-step throughput, same-box A/B)
-        __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(sC + row * BN + cc * 8), reinterpret_cast<u32x4*>(out + (size_t)(m_base + rem) * p.Cout + c));
+        __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(sC + row * SC_LD + cc * 8), reinterpret_cast<u32x4*>(out + (size_t)(m_base + rem) * p.Cout + c));
     }
   }
 
+  DIGA_TCLK(6);
+#ifdef DIGA_TILE_CLOCK
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DIGA_TCLK(7);
+  if (tid == 0 && blockIdx.x < 16384)
+  {
+    for (int i = 0; i < 8; ++i) g_tile_clock[(size_t)blockIdx.x * 16 + i] = tclk[i];
+    g_tile_clock[(size_t)blockIdx.x * 16 + 10] = sclk1 - sclk0;     // shader-clock cycles of the K loop
+  }
+#endif
   if constexpr (STATS) {
     if (p.fin_ticket) {
       // ---- fused DAM finalize.  The XCDs' L2s are not coherent with each other inside a launch: this block's slab values went
@@ -560,7 +641,7 @@ int auto_tile(const diga_conv_desc* d) {
 template <int BM, int BN, int WM, int WN, int S, int BK = 64, bool ILV = false>
 int launch_cfg(const ConvKParams& p, int splitk, int epi, hipStream_t st) {
   constexpr int main_bytes = S * (BM + BN) * BK * 2;
-  constexpr int epi_bytes = BM * BN * 2;
+  constexpr int epi_bytes = BM * (DIGA_MF == 16 ? BN + 8 : BN) * 2;
   constexpr int fin_bytes = FIN_PH * 2 * BN * 8;         // the fused finalize's fp64 phase sums
   constexpr int smem01 = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   constexpr int smem = smem01 > fin_bytes ? smem01 : fin_bytes;
@@ -592,7 +673,7 @@ int launch_cfg(const ConvKParams& p, int splitk, int epi, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int BK>
 int launch_fused_in(const ConvKParams& p, int amode, hipStream_t st) {
   constexpr int main_bytes = 2 * (BM + BN) * BK * 2;
-  constexpr int epi_bytes = BM * BN * 2;
+  constexpr int epi_bytes = BM * (DIGA_MF == 16 ? BN + 8 : BN) * 2;
   constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   dim3 grid(p.mtiles * p.ntiles_n, 1), block(64 * WM * WN);
 #define DIGA_FUSED_KERNEL(A) conv_igemm_kernel<BM, BN, WM, WN, 2, BK, false, EPI_BF16_STATS, A>
@@ -815,3 +896,10 @@ extern "C" int diga_conv_igemm_bf16_fused_in(const diga_conv_desc* d, const void
   }
   return run_conv(d, raw_in, wgt, out, stat_slab, stat_shift, EPI_BF16_STATS, nullptr, nullptr, nullptr, 0, 0, stream, FinArgs(), fi);
 }
+
+#ifdef DIGA_TILE_CLOCK
+extern "C" int diga_debug_tile_clock(unsigned long long* host, int nblocks) {
+  if (nblocks > 16384) nblocks = 16384;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tile_clock), (size_t)nblocks * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif

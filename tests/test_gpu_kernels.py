@@ -49,6 +49,10 @@ CONV_CASES = [
     (1, 33, 65, 64, 256, 1, False, 1, 0),
     (2, 17, 33, 128, 64, 1, True, 1, 3),
     (1, 23, 31, 512, 512, 1, True, 4, 0),
+    # 8-wave tiles, 64- and 32-channel K steps
+    (2, 23, 31, 128, 256, 1, True, 2, 48),
+    (1, 33, 65, 64, 256, 1, False, 1, 66),
+    (3, 9, 17, 256, 512, 1, False, 1, 57),
 ]
 
 
