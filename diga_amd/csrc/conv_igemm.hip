@@ -596,6 +596,186 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weights-stationary 1x1 convolution for short K (Cin = 64 / 128 / 256, stride 1: the bottlenecks' conv3), tile id 91.
+//
+// The tiled kernel above spends most of a K = 256 tile outside its K loop (prologue latency, statistics, staging, stores:
+// 532 TFLOP/s on layer3.conv3 at 15 frames).  Here a block keeps its 128-column slice of the weights in LDS for its whole
+// life (whole K: <= 64 KiB, swizzled as above) and its 8 waves run INDEPENDENTLY, no block barrier after the weights have
+// landed: a wave takes one statistics unit (32 rows of one sample) at a time, streams the unit's A fragments global ->
+// registers (16 KiB in flight per wave, the next unit's loads issued as this unit's registers retire), multiplies against
+// the resident weights, takes the unit's statistics, stages its 32 x 128 outputs through its own 8.5 KiB of LDS and stores
+// 256-byte row pieces.  Waves drift apart, so one wave's epilogue runs under the MFMAs of the wave it shares a SIMD with.
+// The K order of every output element (32-channel MFMA steps, ascending) and the statistics tree are those of the tiled
+// kernel: outputs and slab are bit-identical (tests/test_gpu_kernels.py).
+// Grid = (unit groups) x (Cout / 128) blocks; the slices of one unit group get consecutive logical ids = one XCD, whose L2
+// serves the re-reads of the group's A rows.
+template <int KC>
+__global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, int units_total, int units_per_group) {
+  constexpr int BN = 128, NTW = BN / 16, KS = KC / 32;
+  constexpr int ROWB = KC * 2, B_BYTES = BN * ROWB;
+  constexpr int SW_LD = BN + 8, SW_BYTES = 32 * SW_LD * 2;     // a wave's staging tile: 32 rows, 16 bytes of padding per row
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, fq = lane >> 4;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int nslices = p.Cout / BN;
+  const int grp = bid / nslices, n0 = (bid - grp * nslices) * BN;
+  const int u_begin = grp * units_per_group, u_end = min(u_begin + units_per_group, units_total);
+
+  // ---- the weight slice -> LDS, whole K: row r (output channel n0 + r) = ROWB bytes, 16-byte chunk c stored in slot c ^ f(r)
+  // (f = r & 15, or (r >> 1) & 7 for 128-byte rows): a ds_read_b128 of 16 consecutive rows at one chunk is conflict-free
+  auto bswz = [](int row) { return KC == 64 ? (row >> 1) & 7 : row & 15; };
+  {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    const unsigned short* wgt = reinterpret_cast<const unsigned short*>(p.wgt);
+#pragma unroll
+    for (int i = 0; i < B_BYTES / 8192; ++i) {
+      const int off = (wave + 8 * i) * 1024 + lane * 16;
+      const int row = off / ROWB, slot = (off % ROWB) >> 4;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(wgt + (size_t)(n0 + row) * KC + ((slot ^ bswz(row)) << 3)),
+                                       (lds_ptr)(smem + (wave + 8 * i) * 1024), 16, 0, 0);
+    }
+  }
+  float ksh[NTW];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) ksh[n] = p.shift[n0 + n * 16 + l15];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const unsigned short* const in = reinterpret_cast<const unsigned short*>(p.in);
+  unsigned short* const out = reinterpret_cast<unsigned short*>(p.out);
+  unsigned short* const sW = reinterpret_cast<unsigned short*>(smem + B_BYTES + wave * SW_BYTES);
+  const unsigned char* const bB = smem + l15 * ROWB;
+  const int b_swz = bswz(l15);                       // column tiles start at multiples of 16 rows: the swizzle depends on l15 only
+
+  // A fragments of one unit: M tile a (16 rows), K step k: lane (l15, fq) holds channels 32k + 8fq .. + 7 of row 16a + l15
+  u32x4 fa[KS][2];
+  auto unit_rows = [&](int u, const unsigned short** rp) {
+    const int n_img = u / p.units_per_sample, ubase = (u - n_img * p.units_per_sample) * 32;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int row = min(ubase + a * 16 + l15, p.hw - 1);      // rows beyond the sample: any valid address, never used
+      rp[a] = in + ((size_t)n_img * p.hw + row) * KC + fq * 8;
+    }
+  };
+  int u = u_begin + wave;
+  if (u < u_end) {
+    const unsigned short* rp[2];
+    unit_rows(u, rp);
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[k][a] = *reinterpret_cast<const u32x4*>(rp[a] + k * 32);
+  }
+  for (; u < u_end; u += 8) {
+    const int un = u + 8 < u_end ? u + 8 : u;         // the last unit re-reads itself: no branch in the body
+    const unsigned short* rp[2];
+    unit_rows(un, rp);
+    f32x4 acc[2][NTW];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int coff = ((4 * k + fq) ^ b_swz) << 4;
+      bf16x8 fb[NTW];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(bB + n * 16 * ROWB + coff);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, fa[k][a]);
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, fb[n], acc[a][n], 0, 0, 0);
+      }
+      // this K step's registers are free: the next unit's fragments go into them while the remaining steps run
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[k][a] = *reinterpret_cast<const u32x4*>(rp[a] + k * 32);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- the unit's statistics (the tree of the tiled kernel) and its 32 x 128 outputs
+    const int n_img = u / p.units_per_sample, ubase = (u - n_img * p.units_per_sample) * 32;
+    const bool full = ubase + 32 <= p.hw;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      float sg[2], qg[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        float d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d[i] = acc[a][n][i] - ksh[n];
+          if (!full && ubase + a * 16 + 4 * fq + i >= p.hw) d[i] = 0.f;
+        }
+        sg[a] = (d[0] + d[1]) + (d[2] + d[3]);
+        qg[a] = fmaf(d[1], d[1], d[0] * d[0]) + fmaf(d[3], d[3], d[2] * d[2]);
+      }
+      float t1 = sg[0] + sg[1], t2 = qg[0] + qg[1];
+      t1 += __shfl_xor(t1, 32);
+      t2 += __shfl_xor(t2, 32);
+      t1 += __shfl_xor(t1, 16);
+      t2 += __shfl_xor(t2, 16);
+      if (fq < 2) p.slab[((size_t)u * 2 + fq) * p.Cout + n0 + n * 16 + l15] = fq ? t2 : t1;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sW[(a * 16 + 4 * fq + i) * SW_LD + n * 16 + l15] = f32_to_bf16_bits(acc[a][n][i]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's staging writes are done (LDS ops of one wave stay in order)
+    __builtin_amdgcn_wave_barrier();
+    const size_t orow = (size_t)n_img * p.hw + ubase;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = i * 4 + (lane >> 4), cc = lane & 15;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(sW + row * SW_LD + cc * 8);
+      if (ubase + row < p.hw)
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + (orow + row) * p.Cout + n0 + cc * 8));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging tile has been read: the next unit may overwrite it
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+int launch_ws(const diga_conv_desc* d, const ConvKParams& p, int epi, hipStream_t st) {
+  DIGA_CHECK_ARG(d->ntaps == 1 && d->stride == 1 && d->dy[0] == 0 && d->dx[0] == 0 && d->H == d->Ho && d->W == d->Wo,
+                 "diga_conv_igemm_bf16: tile 91 (weights-stationary) is for 1x1 stride-1 convolutions");
+  DIGA_CHECK_ARG((d->Cin == 64 || d->Cin == 128 || d->Cin == 256) && d->Cout % 128 == 0 && d->cout_pad == d->Cout,
+                 "diga_conv_igemm_bf16: tile 91 needs Cin in {64, 128, 256} and Cout %% 128 == 0 (got %d -> %d)", d->Cin, d->Cout);
+  DIGA_CHECK_ARG(epi == EPI_BF16_STATS && p.nterms == 1 && d->splitk == 1 && p.fin_ticket == nullptr,
+                 "diga_conv_igemm_bf16: tile 91 has the trunk epilogue only (bf16 output + statistics)");
+  const int units_total = d->B * p.units_per_sample, nslices = d->Cout / 128;
+  // one block per CU (its LDS): as many unit groups as fill the chip once, at least 8 units (one per wave) per group
+  int groups = 256 / nslices;
+  if (groups < 1) groups = 1;
+  if (groups > cdiv(units_total, 8)) groups = cdiv(units_total, 8);
+  const int upg = cdiv(units_total, groups);
+  groups = cdiv(units_total, upg);
+  const int smem = 128 * d->Cin * 2 + 8 * 32 * (128 + 8) * 2;
+  dim3 grid(groups * nslices), block(512);
+#define DIGA_WS_LAUNCH(KC)                                                                                              \
+  {                                                                                                                     \
+    static std::once_flag once;                                                                                         \
+    std::call_once(once, [&] {                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                128 * KC * 2 + 8 * 32 * (128 + 8) * 2);                                                 \
+    });                                                                                                                 \
+    hipLaunchKernelGGL(conv1x1_ws_kernel<KC>, grid, block, smem, st, p, units_total, upg);                              \
+  }
+  if (d->Cin == 64) DIGA_WS_LAUNCH(64)
+  else if (d->Cin == 128) DIGA_WS_LAUNCH(128)
+  else DIGA_WS_LAUNCH(256)
+#undef DIGA_WS_LAUNCH
+  return DIGA_OK;
+}
+
 struct TileCfg {
   int id, BM, BN, S, BK = 64;
   bool ilv = false;
@@ -620,7 +800,9 @@ const TileCfg kTiles[] = {{1, 128, 128, 4}, {11, 128, 128, 3}, {21, 128, 128, 2}
                           // one block's epilogue overlaps another's K loop (the short-K 1x1 convs: K = 256 is 4-8 steps per tile)
                           {61, 128, 128, 2, 32, false}, {64, 64, 128, 2, 32, false}, {66, 256, 128, 2, 32, true}, {67, 128, 256, 2, 32, true},
                           // ids 76 / 77: the shapes of 66 / 67 without interleaved issue -- the fused-input kernels only
-                          {76, 256, 128, 2, 32, false}, {77, 128, 256, 2, 32, false}};
+                          {76, 256, 128, 2, 32, false}, {77, 128, 256, 2, 32, false},
+                          // id 91: conv1x1_ws_kernel (weights-stationary 1x1, Cin <= 256); BM = its 32-row units
+                          {91, 32, 128, 1, 64, false}};
 
 const TileCfg* find_tile(int id) {
   for (const auto& t : kTiles)
@@ -795,6 +977,11 @@ int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out
     }
     if (e) return e;
     DIGA_CHECK_LAUNCH("diga_conv_igemm_bf16_fused_in");
+    return DIGA_OK;
+  }
+  if (t->id == 91) {
+    if (int e91 = launch_ws(d, p, epi, st)) return e91;
+    DIGA_CHECK_LAUNCH("diga_conv_igemm_bf16");
     return DIGA_OK;
   }
 #define DIGA_TILE_CASES(base, BM, BN, WM, WN)                                                   \

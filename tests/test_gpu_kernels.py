@@ -130,6 +130,42 @@ def test_conv_results_do_not_depend_on_tile_or_batch():
         assert torch.equal(o[0], o0[b]) and torch.equal(sl[0].view(torch.int32), s0[b].view(torch.int32)), b
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 13, 21, 256, 256), (2, 9, 17, 128, 512), (1, 33, 65, 64, 256), (4, 7, 5, 256, 1024)])
+def test_weights_stationary_1x1_is_bit_identical(B, H, W, Cin, Cout):
+    """Tile id 91 (conv1x1_ws_kernel: weights resident in LDS, one wave per 32-row statistics unit) against the tiled kernel:
+    raw output and statistics slab bit-identical, ragged last unit of every sample included; shapes it does not cover are
+    refused with an error."""
+    g = torch.Generator().manual_seed(B * 100 + Cin + Cout)
+    x = bf16_round(torch.randn(B, Cin, H, W, generator=g).relu() + 0.1 * torch.randn(B, Cin, H, W, generator=g))
+    wt = bf16_round(torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5)
+    wp = pack_conv_weight(wt).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    xin = to_nhwc_bf16(x)
+
+    def run(tile):
+        d = conv_desc(B, H, W, Cin, Cout, 1, False, 1, tile=tile)
+        nu = call("diga_conv_stat_units", C.byref(d))
+        out = torch.full((B * H * W * Cout,), float("nan"), dtype=torch.bfloat16, device=DEV)
+        slab = torch.full((nu * 2 * Cout,), float("nan"), dtype=torch.float32, device=DEV)
+        call("diga_conv_igemm_bf16", C.byref(d), P(xin), P(wp), P(out), P(slab), P(shift), stream())
+        torch.cuda.synchronize()
+        return out.view(torch.int16).cpu(), slab.cpu()
+
+    o0, s0 = run(23)
+    o1, s1 = run(91)
+    assert not torch.isnan(s1).any()
+    assert torch.equal(o0, o1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    ref = F.conv2d(x, wt)
+    assert rel_err(from_nhwc_bf16(o1.view(torch.bfloat16).to(DEV), (B, H, W, Cout)), bf16_round(ref)) <= BF16_TOL
+    # a 3x3 conv / Cin = 512 has no weights-stationary kernel: refused, not silently mis-run
+    d = conv_desc(B, H, W, Cin, Cout, 1, True, 1, tile=91)
+    w9 = torch.zeros(Cout * 9 * Cin, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(B * H * W * Cout, dtype=torch.bfloat16, device=DEV)
+    slab = torch.zeros(call("diga_conv_stat_units", C.byref(d)) * 2 * Cout, dtype=torch.float32, device=DEV)
+    with pytest.raises(Exception, match="tile 91"):
+        call("diga_conv_igemm_bf16", C.byref(d), P(xin), P(w9), P(out), P(slab), P(shift), stream())
+
+
 @pytest.mark.parametrize("B,per_sample,tile", [(1, 0, 0), (3, 1, 48), (2, 0, 24), (2, 1, 67)])
 def test_conv3_two_pass_fused_apply(B, per_sample, tile):
     """conv3 -> bn3 -> += residual -> relu as two passes over the GEMM: pass 1 (out = NULL) leaves exactly the slab of the
