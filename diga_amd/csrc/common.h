@@ -40,8 +40,11 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(unsigned short, b);
 }
+// two roundings in ONE v_cvt_pk_bf16_f32 (separate scalar conversions cost one instruction each)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ void unpack_bf16x8(const u32x4& v, float* f) {
 #pragma unroll

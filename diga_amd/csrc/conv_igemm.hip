@@ -91,6 +91,51 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---- DAM statistics of one unit (32 consecutive rows of a sample x one channel), summed in ONE fixed tree whatever the
+// tile shape, the MFMA shape or the kernel, so that a unit's bits never depend on who produced it:
+//   4-row group g (rows 4g .. 4g+3), d = x - shift[c]:   S_g = (d0 + d2) + (d1 + d3),   Q_g = fma(d2, d2, d0*d0) + fma(d3, d3, d1*d1)
+//   unit = [(g0 + g4) + (g2 + g6)] + [(g1 + g5) + (g3 + g7)]      (S and Q alike)
+// Both accumulator layouts keep whole 4-row groups in one lane (32x32x16: registers 4q .. 4q+3 of lane half hh = group 2q + hh;
+// 16x16x32: lane group fq of the unit's two 16-row tiles = groups fq and 4 + fq), so a group is packed fp32 arithmetic on register
+// pairs (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) and the rest of the tree is one or two cross-lane adds.
+// (S_g, Q_g) of one group; valid = bit i set when row i of the group is inside the sample (rows beyond it contribute d = 0)
+// (FULL: the whole unit is inside the sample -- a wave-uniform fact, so callers branch on it ONCE per unit instead of
+// letting the compiler turn the masking into selects on every element)
+template <bool FULL>
+__device__ __forceinline__ f32x2 stat_group(float x0, float x1, float x2, float x3, float k, unsigned valid) {
+  const f32x2 kk = {k, k};
+  f32x2 A = f32x2{x0, x1} - kk, B = f32x2{x2, x3} - kk;
+  if constexpr (!FULL) {
+    A[0] = (valid & 1u) ? A[0] : 0.f;
+    A[1] = (valid & 2u) ? A[1] : 0.f;
+    B[0] = (valid & 4u) ? B[0] : 0.f;
+    B[1] = (valid & 8u) ? B[1] : 0.f;
+  }
+#ifdef DIGA_STAT_SCALAR
+  const float s = (A[0] + B[0]) + (A[1] + B[1]);
+  const float q = fmaf(B[0], B[0], A[0] * A[0]) + fmaf(B[1], B[1], A[1] * A[1]);
+  return f32x2{s, q};
+#else
+  const f32x2 P = A + B, F = __builtin_elementwise_fma(B, B, A * A);
+  return f32x2{P[0] + P[1], F[0] + F[1]};
+#endif
+}
+// Cross-lane part.  gfx950 lane swaps instead of __shfl_xor's ds_bpermute (an LDS round trip per call); inline asm because the
+// __builtin_amdgcn_permlane*_swap builtins of this toolchain return the first result twice.
+// t = (S, Q) partial of this lane -> lanes 0-31: S(lane) + S(lane + 32), lanes 32-63: Q(lane - 32) + Q(lane): ONE swap folds
+// both sums (v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second)
+__device__ __forceinline__ float stat_fold32(f32x2 t) {
+  float a = t[0], b = t[1];
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = [S.lo | Q.lo], b = [S.hi | Q.hi]
+  return a + b;
+}
+// x + (x of lane ^ 16) in every lane (v_permlane16_swap exchanges the odd 16-lane rows of a with the even rows of b)
+__device__ __forceinline__ float xor_add16(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = even rows twice, b = odd rows twice
+  return a + b;
+}
+
 // Epilogue modes: 0 = bf16 output + statistics (the trunk), 1 = fp32 output (head GEMM / split-K partials),
 // 2 = bf16 output only, 3 = statistics only (nothing stored: pass 1 of a recomputed conv3), 4 = fused DAM apply:
 // out = relu(acc*scale[c] + shift[c] + residual) in bf16, straight from the fp32 accumulators (pass 2).
@@ -397,13 +442,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
   // ------------------------------------------------------------------ epilogue
   // accumulator element r of tile (a,b): row = wm*WTM + acc_row(a, r), col = wn*WTN + acc_col(b)
   if constexpr (STATS) {
-    // One statistics unit = 32 consecutive rows of the sample x one channel, summed in ONE fixed tree whatever the tile
-    // shape and the MFMA shape, so that a unit's bits do not depend on which kernel produced it:
-    //   rows 4g .. 4g+3 (g = 0..7):  S_g = (d0 + d1) + (d2 + d3),  Q_g = fma(d1, d1, d0*d0) + fma(d3, d3, d2*d2),  d = x - shift[c]
-    //   unit = [(g0 + g4) + (g2 + g6)] + [(g1 + g5) + (g3 + g7)]
-    // Both accumulator layouts keep whole 4-row groups in one lane: 32x32x16 has groups hh, 2+hh, 4+hh, 6+hh (registers
-    // 4q .. 4q+3 = group 2q + hh), 16x16x32 has group fq of each of the unit's two 16-row tiles (fq and 4 + fq); the rest
-    // of the tree is one (32x32) or two (16x16) cross-lane adds.  Rows beyond the sample contribute d = 0.
+    // one statistics unit per 32 rows (stat_group / stat_fold32 above); lanes 0-31 end up with the unit's sum, lanes 32-63 with
+    // its sum of squares, for the column they own
     constexpr int UT = 32 / MF;                           // MFMA tile rows per unit: 1 or 2
 #pragma unroll
     for (int ua = 0; ua < MT / UT; ++ua) {
@@ -411,48 +451,42 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
       if (ubase < p.hw) {
         const bool full = ubase + 32 <= p.hw;
         const size_t urow = ((size_t)n_img * p.units_per_sample + (ubase >> 5)) * 2;
+        auto unit_stats = [&](auto full_c) {
+          constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-        for (int b = 0; b < NT; ++b) {
-          const int c = n0 + wn * WTN + acc_col(b);
-          const float kshift = c < p.Cout ? p.shift[c] : 0.f;
-          // group sums of the 4 registers acc[a][b][4q .. 4q+3], whose first row inside the unit is `row0`
-          auto group = [&](int a, int q, int row0, float& sg, float& qg) {
-            float d[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              d[i] = acc[a][b][4 * q + i] - kshift;
-              if (!full && ubase + row0 + i >= p.hw) d[i] = 0.f;
+          for (int b = 0; b < NT; ++b) {
+            const int c = n0 + wn * WTN + acc_col(b);
+            const float kshift = c < p.Cout ? p.shift[c] : 0.f;
+            // the group held in registers 4q .. 4q+3 of tile (a, b), whose first row inside the unit is row0
+            auto group = [&](int a, int q, int row0) {
+              unsigned valid = 15u;
+              if constexpr (!FULL) {
+                const int left = p.hw - (ubase + row0);     // rows of this group inside the sample
+                valid = left >= 4 ? 15u : left <= 0 ? 0u : (1u << left) - 1u;
+              }
+              return stat_group<FULL>(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3], kshift, valid);
+            };
+            float w;
+            if constexpr (MF == 32) {
+              const f32x2 g0 = group(ua, 0, 4 * hh), g1 = group(ua, 1, 8 + 4 * hh), g2 = group(ua, 2, 16 + 4 * hh), g3 = group(ua, 3, 24 + 4 * hh);
+              w = stat_fold32((g0 + g2) + (g1 + g3));       // (g_hh + g_4+hh) + (g_2+hh + g_6+hh), then hh = 0 + hh = 1
+            } else {
+              const f32x2 ga = group(2 * ua, 0, 4 * hh), gb = group(2 * ua + 1, 0, 16 + 4 * hh);   // groups fq and 4 + fq
+              w = xor_add16(stat_fold32(ga + gb));          // + the pair of fq ^ 2, then even groups + odd groups
             }
-            sg = (d[0] + d[1]) + (d[2] + d[3]);
-            qg = fmaf(d[1], d[1], d[0] * d[0]) + fmaf(d[3], d[3], d[2] * d[2]);
-          };
-          float t1, t2;
-          if constexpr (MF == 32) {
-            float sg[4], qg[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) group(ua, q, 8 * q + 4 * hh, sg[q], qg[q]);
-            t1 = (sg[0] + sg[2]) + (sg[1] + sg[3]);       // (g_hh + g_4+hh) + (g_2+hh + g_6+hh)
-            t2 = (qg[0] + qg[2]) + (qg[1] + qg[3]);
-            t1 += __shfl_xor(t1, 32);
-            t2 += __shfl_xor(t2, 32);
-          } else {
-            float s0, q0, s1, q1;
-            group(2 * ua, 0, 4 * hh, s0, q0);             // group fq
-            group(2 * ua + 1, 0, 16 + 4 * hh, s1, q1);    // group 4 + fq
-            t1 = s0 + s1;
-            t2 = q0 + q1;
-            t1 += __shfl_xor(t1, 32);                     // + the pair of fq ^ 2
-            t2 += __shfl_xor(t2, 32);
-            t1 += __shfl_xor(t1, 16);                     // even groups + odd groups
-            t2 += __shfl_xor(t2, 16);
+            if (c < p.Cout) {                               // (16x16x32: lanes fq and fq ^ 1 store the same word)
+              float* const dst = &p.slab[(urow + (lane >> 5)) * p.Cout + c];
+              if (p.fin_ticket)      // read back inside this launch by another block, maybe on another XCD: write through
+                __hip_atomic_store(dst, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else
+                *dst = w;
+            }
           }
-          if (c < p.Cout && hh < 2) {
-            if (p.fin_ticket)      // read back inside this launch by another block, maybe on another XCD: write through
-              __hip_atomic_store(&p.slab[(urow + hh) * p.Cout + c], hh ? t2 : t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else
-              p.slab[(urow + hh) * p.Cout + c] = hh ? t2 : t1;
-          }
-        }
+        };
+        if (full)
+          unit_stats(std::true_type{});
+        else
+          unit_stats(std::false_type{});
       }
     }
   }
@@ -614,8 +648,12 @@ template <int KC>
 __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, int units_total, int units_per_group) {
   constexpr int BN = 128, NTW = BN / 16, KS = KC / 32;
   constexpr int ROWB = KC * 2, B_BYTES = BN * ROWB;
-  constexpr int SW_LD = BN + 8, SW_BYTES = 32 * SW_LD * 2;     // a wave's staging tile: 32 rows, 16 bytes of padding per row
+  constexpr int SW_LD = BN + 8;                                // a wave's staging tile: 32 rows, 16 bytes of padding per row,
+  constexpr int SW_BYTES = 32 * SW_LD * 2 + 2 * BN * 4;        // + the unit's 2 x 128 statistics words (one 16-byte store per lane)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef DIGA_TILE_CLOCK
+  const unsigned long long wk0 = wall_clock64();
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, fq = lane >> 4;
@@ -652,6 +690,7 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
   const unsigned short* const in = reinterpret_cast<const unsigned short*>(p.in);
   unsigned short* const out = reinterpret_cast<unsigned short*>(p.out);
   unsigned short* const sW = reinterpret_cast<unsigned short*>(smem + B_BYTES + wave * SW_BYTES);
+  float* const sS = reinterpret_cast<float*>(smem + B_BYTES + wave * SW_BYTES + 32 * SW_LD * 2);
   const unsigned char* const bB = smem + l15 * ROWB;
   const int b_swz = bswz(l15);                       // column tiles start at multiples of 16 rows: the swizzle depends on l15 only
 
@@ -674,7 +713,18 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
 #pragma unroll
       for (int a = 0; a < 2; ++a) fa[k][a] = *reinterpret_cast<const u32x4*>(rp[a] + k * 32);
   }
+#ifdef DIGA_TILE_CLOCK
+  unsigned long long wc[4] = {0, 0, 0, 0}, wt0 = clock64(), wr0 = wall_clock64();
+#define DIGA_WCLK(i, t0) wc[i] += clock64() - (t0)
+#else
+#define DIGA_WCLK(i, t0) \
+  do {                  \
+  } while (0)
+#endif
   for (; u < u_end; u += 8) {
+#ifdef DIGA_TILE_CLOCK
+    const unsigned long long c0 = clock64();
+#endif
     const int un = u + 8 < u_end ? u + 8 : u;         // the last unit re-reads itself: no branch in the body
     const unsigned short* rp[2];
     unit_rows(un, rp);
@@ -683,6 +733,8 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int n = 0; n < NTW; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (plain loads: the compiler counts them.  Issuing and counting them by hand -- vmcnt(2 (KS - 1) + stores per unit), so
+    // that a K step never waits for the previous unit's stores -- was built and measured: no gain, 105 vs 107 us)
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       const int coff = ((4 * k + fq) ^ b_swz) << 4;
@@ -700,48 +752,81 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
       for (int a = 0; a < 2; ++a) fa[k][a] = *reinterpret_cast<const u32x4*>(rp[a] + k * 32);
       __builtin_amdgcn_sched_barrier(0);
     }
-
+    DIGA_WCLK(0, c0);
+#ifdef DIGA_TILE_CLOCK
+    const unsigned long long c1 = clock64();
+#endif
     // ---- the unit's statistics (the tree of the tiled kernel) and its 32 x 128 outputs
     const int n_img = u / p.units_per_sample, ubase = (u - n_img * p.units_per_sample) * 32;
     const bool full = ubase + 32 <= p.hw;
+    auto unit_stats = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
+      unsigned va = 15u, vb = 15u;                     // rows of this lane's two groups inside the sample (ragged last unit)
+      if constexpr (!FULL) {
+        const int la = p.hw - (ubase + 4 * fq), lb = la - 16;
+        va = la >= 4 ? 15u : la <= 0 ? 0u : (1u << la) - 1u;
+        vb = lb >= 4 ? 15u : lb <= 0 ? 0u : (1u << lb) - 1u;
+      }
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        const f32x2 ga = stat_group<FULL>(acc[0][n][0], acc[0][n][1], acc[0][n][2], acc[0][n][3], ksh[n], va);
+        const f32x2 gb = stat_group<FULL>(acc[1][n][0], acc[1][n][1], acc[1][n][2], acc[1][n][3], ksh[n], vb);
+        const float w = xor_add16(stat_fold32(ga + gb));
+        // lanes 0-31 hold the unit's sum, lanes 32-63 its sum of squares (lanes fq and fq ^ 1 the same word): collected in
+        // LDS and stored below with ONE 16-byte store per lane -- store instructions, not bytes, are what an epilogue pays for
+        sS[(lane >> 5) * BN + n * 16 + l15] = w;
+      }
+    };
+    if (full)
+      unit_stats(std::true_type{});
+    else
+      unit_stats(std::false_type{});
+    DIGA_WCLK(3, c1);
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
-      float sg[2], qg[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        float d[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          d[i] = acc[a][n][i] - ksh[n];
-          if (!full && ubase + a * 16 + 4 * fq + i >= p.hw) d[i] = 0.f;
-        }
-        sg[a] = (d[0] + d[1]) + (d[2] + d[3]);
-        qg[a] = fmaf(d[1], d[1], d[0] * d[0]) + fmaf(d[3], d[3], d[2] * d[2]);
-      }
-      float t1 = sg[0] + sg[1], t2 = qg[0] + qg[1];
-      t1 += __shfl_xor(t1, 32);
-      t2 += __shfl_xor(t2, 32);
-      t1 += __shfl_xor(t1, 16);
-      t2 += __shfl_xor(t2, 16);
-      if (fq < 2) p.slab[((size_t)u * 2 + fq) * p.Cout + n0 + n * 16 + l15] = fq ? t2 : t1;
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sW[(a * 16 + 4 * fq + i) * SW_LD + n * 16 + l15] = f32_to_bf16_bits(acc[a][n][i]);
+        for (int i = 0; i < 4; i += 2) {
+          const unsigned pk = pack_bf16x2(acc[a][n][i], acc[a][n][i + 1]);      // rows i, i + 1 of the same column
+          sW[(a * 16 + 4 * fq + i) * SW_LD + n * 16 + l15] = (unsigned short)pk;
+          sW[(a * 16 + 4 * fq + i + 1) * SW_LD + n * 16 + l15] = (unsigned short)(pk >> 16);
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's staging writes are done (LDS ops of one wave stay in order)
     __builtin_amdgcn_wave_barrier();
+    DIGA_WCLK(1, c1);
+#ifdef DIGA_TILE_CLOCK
+    const unsigned long long c2 = clock64();
+#endif
     const size_t orow = (size_t)n_img * p.hw + ubase;
+    u32x4 ov[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = i * 4 + (lane >> 4), cc = lane & 15;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(sW + row * SW_LD + cc * 8);
-      if (ubase + row < p.hw)
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + (orow + row) * p.Cout + n0 + cc * 8));
+    for (int i = 0; i < 8; ++i) ov[i] = *reinterpret_cast<const u32x4*>(sW + (i * 4 + (lane >> 4)) * SW_LD + (lane & 15) * 8);
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(sS + lane * 4);          // row lane >> 5, columns 4 (lane & 31) .. + 3
+    *reinterpret_cast<f32x4*>(&p.slab[((size_t)u * 2 + (lane >> 5)) * p.Cout + n0 + (lane & 31) * 4]) = sv;
+    unsigned short* const orp = out + (orow + (lane >> 4)) * p.Cout + n0 + (lane & 15) * 8;
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(ov[i], reinterpret_cast<u32x4*>(orp + (size_t)i * 4 * p.Cout));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (ubase + i * 4 + (lane >> 4) < p.hw) __builtin_nontemporal_store(ov[i], reinterpret_cast<u32x4*>(orp + (size_t)i * 4 * p.Cout));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging tile has been read: the next unit may overwrite it
     __builtin_amdgcn_wave_barrier();
+    DIGA_WCLK(2, c2);
   }
+#ifdef DIGA_TILE_CLOCK
+  if (lane == 0 && blockIdx.x < 2048) {
+    unsigned long long* g = g_tile_clock + ((size_t)blockIdx.x * 8 + wave) * 8;
+    g[0] = wc[0], g[1] = wc[1], g[2] = wc[2], g[3] = clock64() - wt0, g[4] = wall_clock64() - wr0;
+    g[5] = (u_end - u_begin - wave + 7) / 8;
+    g[6] = wc[3];
+    g[7] = wr0 - wk0;
+  }
+#endif
 }
 
 int launch_ws(const diga_conv_desc* d, const ConvKParams& p, int epi, hipStream_t st) {
@@ -758,14 +843,14 @@ int launch_ws(const diga_conv_desc* d, const ConvKParams& p, int epi, hipStream_
   if (groups > cdiv(units_total, 8)) groups = cdiv(units_total, 8);
   const int upg = cdiv(units_total, groups);
   groups = cdiv(units_total, upg);
-  const int smem = 128 * d->Cin * 2 + 8 * 32 * (128 + 8) * 2;
+  const int smem = 128 * d->Cin * 2 + 8 * (32 * (128 + 8) * 2 + 2 * 128 * 4);
   dim3 grid(groups * nslices), block(512);
 #define DIGA_WS_LAUNCH(KC)                                                                                              \
   {                                                                                                                     \
     static std::once_flag once;                                                                                         \
     std::call_once(once, [&] {                                                                                          \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                128 * KC * 2 + 8 * 32 * (128 + 8) * 2);                                                 \
+                                128 * KC * 2 + 8 * (32 * (128 + 8) * 2 + 2 * 128 * 4));                                                 \
     });                                                                                                                 \
     hipLaunchKernelGGL(conv1x1_ws_kernel<KC>, grid, block, smem, st, p, units_total, upg);                              \
   }

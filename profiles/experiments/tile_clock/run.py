@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", "..", ".."))
 sys.path.insert(0, os.path.join(HERE, "..", "..", "..", "tests"))
 import diga_amd._lib as L
-L.LIB_PATH = os.path.join(HERE, "libdiga_hip_clock.so")
+L.LIB_PATH = os.path.join(HERE, os.environ.get("CLOCK_LIB", "libdiga_hip_clock.so"))
 import numpy as np, torch
 from gpu_util import DEV, P, call, conv_desc, stream
 from bench_conv import SHAPES, TILE_MN
