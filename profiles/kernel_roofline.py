@@ -25,7 +25,9 @@ for r in rows_all:
     for plain in ("stem_kernel", "proto_pool_kernel", "proto_dist_kernel", "upsample_argmax_hist_kernel"):      # templated on the storage type since round 2
         if key.startswith(plain + "<"):
             key = plain
-    if key.startswith("conv_igemm_kernel"):
+    if key.startswith("conv1x1_ws_kernel"):       # the weights-stationary 1x1 kernel (tile id 91): same work, same row
+        key = "conv_igemm_kernel"
+    elif key.startswith("conv_igemm_kernel"):
         # template arguments: <BM, BN, WM, WN, S, BK, ILV, EPI, AMODE>; AMODE 2 = "bn3 + residual + relu" of the previous block on
         # the operand path (diga_conv_igemm_bf16_fused_in), a bandwidth-bound launch by construction
         args = [a.strip() for a in n[n.index("<") + 1:n.rindex(">")].split(",")] if "<" in n else []
