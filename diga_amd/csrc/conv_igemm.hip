@@ -281,9 +281,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
       const bool ok = (a_mask >> i) & 1u;
       const u32x4 o = ok ? pack_bf16x8(v) : u32x4{0u, 0u, 0u, 0u};
       *reinterpret_cast<u32x4*>(dA + i * NW * 1024) = o;
+#ifndef DIGA_NO_AOUT   /* ablation builds only: timing without the block-input write-back */
       if constexpr (AMODE == 2) {
         if (ok && ntile == 0) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.a_out) + (pixoff[i] + a_tapoff)) = o;
       }
+#endif
     }
   };
 
@@ -372,18 +374,183 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
 
   // ---- K loop: S-deep LDS ring filled by LDS-DMA, one raw barrier per K step, counted vmcnt so that up to
   // D = S-1 tiles stay in flight across the barrier (never __syncthreads(): its fence drains vmcnt to 0).
-#pragma unroll
-  for (int s = 0; s < D; ++s)
-    if (s < nt) issue_next(s);
-  int stage = 0, fill = D % S;
   DIGA_TCLK(1);
   DIGA_TCLK(2);
 #ifdef DIGA_TILE_CLOCK
   const unsigned long long sclk0 = clock64();
 #endif
-  for (int t = 0; t < nt; ++t) {
+  // ---- fused residual input, 1x1, two K steps of operand registers in flight (small M tiles only: the register sets must fit).
+  // The register-staged path above has ONE step of loads in flight, and those loads are the block's HBM reads (raw3 and the
+  // residual: nothing re-reads them), so a step lasts one memory latency: 5.1 us per step on layer3.conv1 at 15 frames.  Here
+  // step t issues the loads of step t + 2, and the block-input write-back of step t is issued AFTER them, so that the counted
+  // wait for step t + 1's weights (LDS-DMA, issued first) leaves both the loads and the stores outstanding.
+  // Issue order per step: weights DMA (t + 1), operand loads (t + 2), write-back (t); the wait at the top of step t + 1 allows
+  // exactly the NA loads and, in the blocks that write back, the A_CH stores to stay in flight (the stores are issued by
+  // every lane -- rows outside the sample write their zeros to the zero page -- so that their number never varies).
+  constexpr bool DEEP = AMODE == 2 && BK == 64 && A_CH <= 2;
+  bool deep = false;
+  if constexpr (DEEP) deep = p.ntaps == 1 && p.nterms == 1 && (nt & 1) == 0 && nt >= 2;
+  if constexpr (DEEP) {
+    if (deep) {
+      constexpr int NA = 4 + 2 * A_CH;               // loads of one operand set: 2 + 2 affine vectors, A_CH raw, A_CH residual chunks
+      constexpr int KCH = 64 / MF, KS = BK / (8 * KCH);
+      const bool wb = ntile == 0;
+      struct RegSet {
+        u32x4 raw[A_CH], rsd[A_CH];
+        f32x4 sc[2], sh[2];
+      };
+      RegSet r0, r1;
+      u32x4 o[A_CH];
+      const float* const scp = p.a_scale + (size_t)n_img * p.a_affine_stride + cch * 8;
+      const float* const shp = p.a_shift + (size_t)n_img * p.a_affine_stride + cch * 8;
+      const unsigned short* const res = reinterpret_cast<const unsigned short*>(p.a_res);
+      unsigned short* const aout = reinterpret_cast<unsigned short*>(p.a_out);
+      // Rows beyond the sample (ih0 = -100000): their loads go to the sample's last row instead (any valid address: the
+      // values are zeroed in storeA) and their write-back stores go to the zero page with a zero step -- every load and store
+      // below is then ONE unconditional instruction, which is what the counted waits rely on (a select between a tensor
+      // address and the zero page turns into a load of the zero page + a drain + a masked load)
+      int ldoff[A_CH];
+      unsigned short* wbp[A_CH];
+      int wbstep[A_CH];
+      unsigned okmask[A_CH];                          // all ones / zero: an AND instead of a branch around the transform
+      {
+        const int oh = (p.hw - 1) / p.Wo, ow = (p.hw - 1) - oh * p.Wo;
+        const int lastoff = ((n_img * p.H + oh * p.stride) * p.W + ow * p.stride) * p.Cin + cch * 8;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+          const bool ok = ih0[i] >= 0;
+          ldoff[i] = ok ? pixoff[i] : lastoff;
+          wbp[i] = ok ? aout + pixoff[i] : const_cast<unsigned short*>(zero);
+          wbstep[i] = ok ? 64 : 0;
+          okmask[i] = ok ? 0xffffffffu : 0u;
+        }
+      }
+      // The operand loads are asm statements: with compiler-visible loads in this loop hipcc guards every use with
+      // s_waitcnt vmcnt(0) (it does not count across the LDS-DMA and the loop's back edge), which drains the very loads that
+      // are meant to stay in flight.  Their completion is counted by wait_b below, and landed() ties the registers to that
+      // wait (cdna_hip_programming.md 7, asm loads: "=v" loads, wait, "+v" tie, sched_barrier).
+      auto loadA = [&](RegSet& r, int tile) {
+        const int c0 = tile * 64;
+        const float *sp = scp + c0, *hp = shp + c0;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.sc[0]) : "v"(sp) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r.sc[1]) : "v"(sp) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.sh[0]) : "v"(hp) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r.sh[1]) : "v"(hp) : "memory");
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+          const unsigned short *rp = in + (ldoff[i] + c0), *qp = res + (ldoff[i] + c0);
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.raw[i]) : "v"(rp) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r.rsd[i]) : "v"(qp) : "memory");   // read for the last time
+        }
+      };
+      auto landed = [&](RegSet& r) {                  // after wait_b: the set's registers hold their data from here on
+        asm volatile("" : "+v"(r.sc[0]), "+v"(r.sc[1]), "+v"(r.sh[0]), "+v"(r.sh[1]), "+v"(r.raw[0]), "+v"(r.rsd[0])::"memory");
+        if constexpr (A_CH == 2) asm volatile("" : "+v"(r.raw[1]), "+v"(r.rsd[1])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto storeA = [&](const RegSet& r, int stg) {   // bn_apply_kernel<1>'s arithmetic, rounded once (as a_store above)
+        unsigned char* const dA = smem + stg * STAGE_BYTES + wave * 1024 + lane * 16;
+        const float sc[8] = {r.sc[0][0], r.sc[0][1], r.sc[0][2], r.sc[0][3], r.sc[1][0], r.sc[1][1], r.sc[1][2], r.sc[1][3]};
+        const float sh[8] = {r.sh[0][0], r.sh[0][1], r.sh[0][2], r.sh[0][3], r.sh[1][0], r.sh[1][1], r.sh[1][2], r.sh[1][3]};
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+          float v[8], q[8];
+          unpack_bf16x8(r.raw[i], v);
+          unpack_bf16x8(r.rsd[i], q);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]) + q[e], 0.f);
+          o[i] = pack_bf16x8(v) & u32x4{okmask[i], okmask[i], okmask[i], okmask[i]};
+          *reinterpret_cast<u32x4*>(dA + i * NW * 1024) = o[i];
+        }
+      };
+      auto issueB = [&](int stg, int tile) {
+        unsigned char* const dB = smem + stg * STAGE_BYTES + A_BYTES + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j)
+          __builtin_amdgcn_global_load_lds((gbl_ptr)(wgt + (wrow_off[j] + tile * 64)), (lds_ptr)(dB + j * NW * 1024), 16, 0, 0);
+      };
+      auto writeback = [&]() {                       // called once per K step, in K order: the pointers walk the channels
+        if (wb) {
+#pragma unroll
+          for (int i = 0; i < A_CH; ++i) {
+            *reinterpret_cast<u32x4*>(wbp[i]) = o[i];  // (zeros onto the zero page for rows outside the sample)
+            wbp[i] += wbstep[i];
+          }
+        }
+      };
+      auto wait_b = [&](bool loads) {                  // the weights of the step about to run have landed; younger ops stay in flight
+        if (loads) {
+          if (wb) wait_vmcnt<NA + A_CH>(); else wait_vmcnt<NA>();
+        } else {
+          if (wb) wait_vmcnt<A_CH>(); else wait_vmcnt<0>();
+        }
+      };
+      auto run_stage = [&](int stg) {
+        const unsigned char* bA = smem + stg * STAGE_BYTES + fa_row;
+        const unsigned char* bB = smem + stg * STAGE_BYTES + fb_row;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int coff = ((KCH * s + hh) ^ fr_swz) << 4;
+          bf16x8 fa[MT], fb[NT];
+#pragma unroll
+          for (int a = 0; a < MT; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(bA + a * MF * ROWB + coff);
+#pragma unroll
+          for (int b = 0; b < NT; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(bB + b * MF * ROWB + coff);
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+              if constexpr (MF == 32)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+              else
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+      };
+      loadA(r0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      issueB(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      loadA(r1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < nt; t += 2) {
+        // even step: tile t, register set 0, LDS stage 0
+        if (t == 0) wait_vmcnt<NA>(); else wait_b(true);
+        landed(r0);
+        storeA(r0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issueB(1, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < nt) loadA(r0, t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        writeback();
+        __builtin_amdgcn_sched_barrier(0);
+        run_stage(0);
+        // odd step: tile t + 1, register set 1, LDS stage 1
+        wait_b(t + 2 < nt);
+        landed(r1);
+        storeA(r1, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) issueB(0, t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 3 < nt) loadA(r1, t + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        writeback();
+        __builtin_amdgcn_sched_barrier(0);
+        run_stage(1);
+      }
+    }
+  }
+  const int nt_generic = deep ? 0 : nt;             // (the generic loop below is skipped when the deep loop ran)
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nt_generic) issue_next(s);
+  int stage = 0, fill = D % S;
+  for (int t = 0; t < nt_generic; ++t) {
     // tile t must have landed: leave at most min(D-1, nt-1-t) younger tiles of THIS wave outstanding
-    const int younger = min(D - 1, nt - 1 - t);
+    const int younger = min(D - 1, nt_generic - 1 - t);
     if (younger >= 2) wait_vmcnt<(D >= 3 ? 2 : 0) * LPT>();
     else if (younger == 1) wait_vmcnt<(D >= 2 ? 1 : 0) * LPT>();
     else wait_vmcnt<0>();
@@ -392,7 +559,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();       // every wave's part of tile t is in LDS; everyone is done reading tile t-1
-    const bool more = t + D < nt;       // K step t+D refills the buffer tile t-1 was read from
+    const bool more = t + D < nt_generic;   // K step t+D refills the buffer tile t-1 was read from
     if (!ILV && more) issue_next(fill);
     const unsigned char* bA = smem + stage * STAGE_BYTES + fa_row;
     const unsigned char* bB = smem + stage * STAGE_BYTES + fb_row;
@@ -406,13 +573,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
       for (int a = 0; a < MT; ++a) fa[a] = *reinterpret_cast<const bf16x8*>(bA + a * MF * ROWB + coff);
 #pragma unroll
       for (int b = 0; b < NT; ++b) fb[b] = *reinterpret_cast<const bf16x8*>(bB + b * MF * ROWB + coff);
-#ifdef DIGA_ILV_FRONT
-      constexpr int IG = KS / 2;        // experiment: the loads ride the first half of the step's MFMA groups only
-#else
-      constexpr int IG = KS;
-#endif
-      if (ILV && more && s < IG)        // this group's share of the next K step's loads, in the shadow of the MFMAs below
-        issue_pieces(fill, std::integral_constant<int, (s < IG ? s : 0) * LPT / IG>{}, std::integral_constant<int, ((s < IG ? s : 0) + 1) * LPT / IG>{});
+      // this group's share of the next K step's loads, in the shadow of the MFMAs below (riding only the first half of the
+      // step's groups, so that the pieces have longer to land, changed nothing: +-2 %, same-box A/B)
+      if (ILV && more) issue_pieces(fill, std::integral_constant<int, s * LPT / KS>{}, std::integral_constant<int, (s + 1) * LPT / KS>{});
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
