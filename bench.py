@@ -359,10 +359,10 @@ def main():
             with open(tpath) as f:
                 tj = json.load(f).get(f"frames_in_flight_{fif}", {})
             traffic = tj.get("hbm_bytes_per_step")
-            traffic_src = {k: tj.get(k) for k in ("collected", "mode", "formula") if k in tj}
+            traffic_src = {k: tj.get(k) for k in ("kernel", "collected", "mode", "formula") if k in tj}
         profiled = (f"one window of {fif} frames, eager launches, one HIP-event pair per launch on the launch stream; the timed steps run "
                     f"{nwin} such window(s) concurrently from a HIP graph")
-        res["roofline"] = {"bound": "mfma", "kernel": (f"conv_igemm_kernel (the {len(meta) - 1} trunk convs with a plain input + the head GEMM of one window"
+        res["roofline"] = {"bound": "mfma", "kernel": (f"the implicit-GEMM launches: conv_igemm_kernel and, for the short-K conv3s, conv1x1_ws_kernel (the {len(meta) - 1} trunk convs with a plain input + the head GEMM of one window"
                                                        + (f"; the {fz_n} fused-residual-input conv1 launches are in roofline_hbm)" if fz_n else ")")),
                            "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                            "traffic": traffic, "traffic_source": traffic_src, "frames": fif, "profiled": profiled,

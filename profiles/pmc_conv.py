@@ -16,7 +16,7 @@ def load(pass_dir):
     names = {}
     path = os.path.join(src, pass_dir, "p_counter_collection.csv")
     for r in csv.DictReader(open(path)):
-        if "conv_igemm_kernel" not in r["Kernel_Name"]:
+        if "conv_igemm_kernel" not in r["Kernel_Name"] and "conv1x1_ws_kernel" not in r["Kernel_Name"]:
             continue
         d = int(r["Dispatch_Id"])
         rows[d][r["Counter_Name"]] = rows[d].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])

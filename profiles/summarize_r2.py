@@ -18,21 +18,37 @@ if os.path.exists(os.path.join(src, "trace2", "t_kernel_stats.csv")):
     shutil.copy(os.path.join(src, "trace2", "t_kernel_stats.csv"), os.path.join(here, "r2_bench_2windows_kernel_stats.csv"))
 
 
-def last_step(path, counter, launches):
-    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and "conv_igemm_kernel" in r["Kernel_Name"]]
+def amode(name):
+    """conv_igemm_kernel<BM, BN, WM, WN, S, BK, ILV, EPI, AMODE, MF>: AMODE 2 = the fused-residual-input conv1 launches"""
+    if "conv1x1_ws_kernel" in name:
+        return 0
+    args = [a.strip() for a in name[name.index("<") + 1:name.rindex(">")].split(",")]
+    return int(args[8]) if len(args) > 8 else 0
+
+
+def last_pass(path, counter):
+    """the igemm launches of the LAST eager pass (105: 104 trunk convs + the head GEMM), split into the plain-input launches
+    (bench.py's `roofline` kernel) and the fused-residual-input conv1 launches (priced against HBM in `roofline_hbm`)"""
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and
+            ("conv_igemm_kernel" in r["Kernel_Name"] or "conv1x1_ws_kernel" in r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    rows = rows[-launches:]
-    return sum(float(r["Counter_Value"]) for r in rows)
+    rows = rows[-L:]
+    plain = [r for r in rows if amode(r["Kernel_Name"]) != 2]
+    fused = [r for r in rows if amode(r["Kernel_Name"]) == 2]
+    return sum(float(r["Counter_Value"]) for r in plain), len(plain), sum(float(r["Counter_Value"]) for r in fused), len(fused)
 
 
 L = 105                                   # 104 trunk convs + the head GEMM, per pass
-f = last_step(os.path.join(src, "fetch", "p_counter_collection.csv"), "FETCH_SIZE", L)
-w = last_step(os.path.join(src, "write", "p_counter_collection.csv"), "WRITE_SIZE", L)
+f, nf, ff, nff = last_pass(os.path.join(src, "fetch", "p_counter_collection.csv"), "FETCH_SIZE")
+w, nw, wf, nwf = last_pass(os.path.join(src, "write", "p_counter_collection.csv"), "WRITE_SIZE")
+assert nf == nw and nff == nwf, (nf, nw, nff, nwf)
 p = os.path.join(here, "conv_traffic.json")
 out = json.load(open(p)) if os.path.exists(p) else {}
 out[f"frames_in_flight_{fif}"] = {
-    "hbm_bytes_per_step": int((2 * f + w) * 1024), "fetch_size_kb_raw": f, "write_size_kb": w, "launches": L,
-    "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 over the igemm launches of the last eager pass (fabric-side bytes, Infinity-Cache hits included)",
+    "hbm_bytes_per_step": int((2 * f + w) * 1024), "fetch_size_kb_raw": f, "write_size_kb": w, "launches": nf,
+    "kernel": "the plain-input igemm launches of one pass (bench.py's `roofline` kernel)",
+    "fused_residual_in": {"hbm_bytes_per_step": int((2 * ff + wf) * 1024), "fetch_size_kb_raw": ff, "write_size_kb": wf, "launches": nff},
+    "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 over the launches of the last eager pass (fabric-side bytes, Infinity-Cache hits included)",
     "mode": f"one window of {fif} frames, eager launches, two separate --pmc passes (profiles/collect_r2.sh)", "collected": prov,
 }
 json.dump(out, open(p, "w"), indent=1)
