@@ -239,9 +239,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
       pixoff[i] = 0;
     }
   }
-  int wrow_off[B_CH];
+  // weight rows: a fixed 32-bit BYTE offset per lane, added to a wave-uniform base that carries the K step -- the address
+  // then needs no vector arithmetic per piece (scalar base + vector offset form of the load)
+  unsigned wrow_off[B_CH];
 #pragma unroll
-  for (int j = 0; j < B_CH; ++j) wrow_off[j] = (n0 + lrow + RPI * NW * j) * p.K + cch * 8;
+  for (int j = 0; j < B_CH; ++j) wrow_off[j] = (unsigned)(((n0 + lrow + RPI * NW * j) * p.K + cch * 8) * 2);
 
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
 #pragma unroll
     for (int j = 0; j < B_CH; ++j) {
       if (A_CH + j < lo || A_CH + j >= hi) continue;
-      __builtin_amdgcn_global_load_lds((gbl_ptr)(wgt + (wrow_off[j] + kk)), (lds_ptr)(dB + j * NW * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(reinterpret_cast<const char*>(wgt + kk) + wrow_off[j]), (lds_ptr)(dB + j * NW * 1024), 16, 0, 0);
     }
   };
   auto advance_next = [&]() {
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
         unsigned char* const dB = smem + stg * STAGE_BYTES + A_BYTES + wave * 1024;
 #pragma unroll
         for (int j = 0; j < B_CH; ++j)
-          __builtin_amdgcn_global_load_lds((gbl_ptr)(wgt + (wrow_off[j] + tile * 64)), (lds_ptr)(dB + j * NW * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_ptr)(reinterpret_cast<const char*>(wgt + tile * 64) + wrow_off[j]), (lds_ptr)(dB + j * NW * 1024), 16, 0, 0);
       };
       auto writeback = [&]() {                       // called once per K step, in K order: the pointers walk the channels
         if (wb) {
