@@ -111,14 +111,8 @@ __device__ __forceinline__ f32x2 stat_group(float x0, float x1, float x2, float 
     B[0] = (valid & 4u) ? B[0] : 0.f;
     B[1] = (valid & 8u) ? B[1] : 0.f;
   }
-#ifdef DIGA_STAT_SCALAR
-  const float s = (A[0] + B[0]) + (A[1] + B[1]);
-  const float q = fmaf(B[0], B[0], A[0] * A[0]) + fmaf(B[1], B[1], A[1] * A[1]);
-  return f32x2{s, q};
-#else
-  const f32x2 P = A + B, F = __builtin_elementwise_fma(B, B, A * A);
+  const f32x2 P = A + B, F = __builtin_elementwise_fma(B, B, A * A);     // (scalar adds / FMAs instead: same time, same-box A/B)
   return f32x2{P[0] + P[1], F[0] + F[1]};
-#endif
 }
 // Cross-lane part.  gfx950 lane swaps instead of __shfl_xor's ds_bpermute (an LDS round trip per call); inline asm because the
 // __builtin_amdgcn_permlane*_swap builtins of this toolchain return the first result twice.
@@ -283,11 +277,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
       const bool ok = (a_mask >> i) & 1u;
       const u32x4 o = ok ? pack_bf16x8(v) : u32x4{0u, 0u, 0u, 0u};
       *reinterpret_cast<u32x4*>(dA + i * NW * 1024) = o;
-#ifndef DIGA_NO_AOUT   /* ablation builds only: timing without the block-input write-back */
       if constexpr (AMODE == 2) {
         if (ok && ntile == 0) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.a_out) + (pixoff[i] + a_tapoff)) = o;
       }
-#endif
     }
   };
 
