@@ -402,11 +402,23 @@ def main():
     del eng, frames
     if rank == 0 and world == 1 and fif * nwin > 1 and not args.no_latency_mode:
         # the same stream with ONE frame per step (no look-ahead): the latency-bound form of configs[1]
-        f1, ms1, e1, _, _ = run_config(args, world, rank, dev, group, weights, 1, max(10, args.steps), min(args.warmup, 10))
+        f1, ms1, e1, fr1, _ = run_config(args, world, rank, dev, group, weights, 1, max(10, args.steps), min(args.warmup, 10))
         res["one_frame_per_step"] = {"value": round(f1, 2), "unit": "frames/s", "ms_per_step": round(ms1, 4),
                                      "whole_path_tflops": round(f1 * gflop_frame / 1e3, 2),
                                      "whole_path_frac": round(f1 * gflop_frame / 1e3 / PEAK_BF16_TFLOPS, 4)}
-        del e1
+        if not args.no_roofline:
+            # its own roofline line: the igemm launches of ONE frame (eager, one event pair per launch) and its bn_apply launches
+            m1, t1, am1, at1 = kernel_profile(e1, fr1, CFG)
+            fl1, tm1 = float(sum(f for _, f in m1)), float(t1.sum())
+            ap = [(nb, float(t)) for (k, nb), t in zip(am1, at1) if k == "bn_apply"]
+            res["one_frame_per_step"]["roofline"] = {
+                "bound": "mfma", "kernel": "the implicit-GEMM launches of one frame (M = 8 385 .. 33 153 rows: 132-528 tiles per launch)",
+                "achieved": round(fl1 / (tm1 * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(fl1 / (tm1 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "launches": len(m1), "avg_launch_us": round(tm1 * 1e3 / len(m1), 2),
+                "kernel_ms": round(tm1, 4),
+                "bn_apply": {"achieved_gbs": round(sum(b for b, _ in ap) / (sum(t for _, t in ap) * 1e-3) / 1e9, 1), "launches": len(ap),
+                             "kernel_ms": round(sum(t for _, t in ap), 4)} if ap else None}
+        del e1, fr1
     if rank == 0 and world == 1 and not args.no_miou:
         # five seeded 30-frame streams through the measured configuration; the +-0.1 bar applies to the MEAN delta (one stream's
         # delta is one draw of the bf16 rounding noise, tests/test_gpu_net.py::test_stream_miou_vs_reference_five_streams)
