@@ -397,8 +397,11 @@ extern "C" int diga_bn_apply(const void* raw, const float* scale, const float* s
   const int ns = nsamples_affine > 0 ? nsamples_affine : 1;
   const int64_t Ms = M / ns;                     // rows handled per grid.y slice
   const int C8 = C / 8, rstep = 256 / C8;
-  int rpb = cdiv(Ms, cdiv(2048, ns));
-  rpb = cdiv(rpb, rstep) * rstep;
+  // Rows per thread: 2 (4 for narrow tensors).  Many small blocks in flight beat long per-thread row walks -- same-box sweep at
+  // 15 frames (profiles/experiments/bench_apply.py): C = 256: 23.7 -> 21.3 us, C = 1024 + residual: 129.8 -> 113.1 us (6.8 TB/s of
+  // algorithmic bytes), C = 2048 + residual: 316 -> 261 us -- but not one row (the thread's 16 scale / shift words are loaded per block)
+  int rpb = (C8 <= 16 ? 4 : 2) * rstep;
+  if (cdiv(Ms, rpb) > 65535) rpb = cdiv(cdiv(Ms, 65535), rstep) * rstep;
   const dim3 grid(cdiv(Ms, rpb), ns), block(256);
   hipStream_t st = (hipStream_t)stream;
   const u32x4* r = (const u32x4*)raw;
