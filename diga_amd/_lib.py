@@ -44,6 +44,7 @@ SIGNATURES = {
     "diga_bn_reduce_slab": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "diga_bn_finalize_sums": (_i, [_vp, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
     "diga_bn_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "diga_bn_finalize_apply": (_i, [_vp, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "diga_bn_stats_nchw_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "diga_bn_apply_nchw_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "diga_bn_relu_maxpool": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

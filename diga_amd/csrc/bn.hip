@@ -142,6 +142,64 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const u32x4* __restrict__
   }
 }
 
+// diga_bn_finalize + diga_bn_apply in ONE launch, for small passes (one frame per step): there both kernels sit at their launch
+// floor (5.1 + 7.0 us on a 4-17 MB tensor), and the slab is small enough for every block to reduce it again.  Block = 64 channels
+// x FIN_PH phases, as bn_finalize_kernel: it derives the affine of its 64 channels (same sums, same order, same arithmetic:
+// bit-identical scale / shift), keeps it in LDS, and applies it to its chunk of rows -- 8 lanes per row (128 contiguous bytes),
+// 128 rows per pass.  The blocks of row chunk 0 also publish scale / shift.  MODE 0: no residual, 1: normalised residual.
+template <int MODE>
+__global__ __launch_bounds__(64 * FIN_PH) void bn_finalize_apply_kernel(
+    const float* __restrict__ slab, int ups, int nsamples, int a_samples, int per_sample, int C, double n_a, double n_b,
+    const float* __restrict__ rmean, const float* __restrict__ rvar, const float* __restrict__ weight, const float* __restrict__ bias,
+    float lam, float eps, float* __restrict__ scale, float* __restrict__ shift, const u32x4* __restrict__ raw,
+    const u32x4* __restrict__ res, u32x4* __restrict__ out, int64_t Ms, int relu, int rows_per_block) {
+  __shared__ double red[FIN_PH][4][64];
+  __shared__ float lsc[64], lsh[64];
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int cbase = blockIdx.x * 64, c = cbase + lane;
+  int a0, a1, b1;
+  if (per_sample) {                  // blockIdx.z = sample
+    a0 = blockIdx.z * ups, a1 = a0 + ups, b1 = a1;
+    scale += (size_t)blockIdx.z * C;
+    shift += (size_t)blockIdx.z * C;
+  } else {
+    a0 = 0, a1 = a_samples * ups, b1 = nsamples * ups;
+  }
+  double s[4];
+  slab_group_sums(slab, a0, a1, b1, C, c, c < C, red, s);
+  if (ph == 0 && c < C) {
+    dam_affine_from_sums(s, c, n_a, n_b, rmean, rvar, weight, bias, lam, eps, lsc - cbase, lsh - cbase);
+    if (blockIdx.y == 0) {
+      scale[c] = lsc[lane];
+      shift[c] = lsh[lane];
+    }
+  }
+  __syncthreads();
+  const int oct = threadIdx.x & 7, rsub = threadIdx.x >> 3, C8 = C >> 3;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sc[i] = lsc[oct * 8 + i];
+    sh[i] = lsh[oct * 8 + i];
+  }
+  const size_t sbase = (size_t)blockIdx.z * Ms * C8 + blockIdx.x * 8 + oct;       // blockIdx.z = 0 unless per_sample
+  const int64_t row0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t row1 = row0 + rows_per_block < Ms ? row0 + rows_per_block : Ms;
+  for (int64_t r = row0 + rsub; r < row1; r += 128) {
+    const size_t idx = sbase + (size_t)r * C8;
+    float v[8], q[8];
+    unpack_bf16x8(__builtin_nontemporal_load(&raw[idx]), v);
+    if (MODE != 0) unpack_bf16x8(__builtin_nontemporal_load(&res[idx]), q);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float y = fmaf(v[i], sc[i], sh[i]);
+      if (MODE == 1) y += q[i];
+      v[i] = relu ? fmaxf(y, 0.f) : y;
+    }
+    out[idx] = pack_bf16x8(v);
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const u32x4* __restrict__ raw, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, u32x4* __restrict__ out,
                                                               int B, int H, int W, int C8, int Ho, int Wo, int per_sample) {
@@ -414,6 +472,37 @@ extern "C" int diga_bn_apply(const void* raw, const float* scale, const float* s
   else
     hipLaunchKernelGGL(bn_apply_kernel<2>, grid, block, 0, st, r, scale, shift, q, res_scale, res_shift, (u32x4*)out, Ms, C8, relu, rpb, ps);
   DIGA_CHECK_LAUNCH("diga_bn_apply");
+  return DIGA_OK;
+}
+
+extern "C" int diga_bn_finalize_apply(const float* slab, int units_per_sample, int nsamples, int a_samples, int per_sample, int C,
+                                      double n_a, double n_b, const float* running_mean, const float* running_var, const float* weight,
+                                      const float* bias, float lam, float eps, float* scale, float* shift, const void* raw,
+                                      const void* res, void* out, int64_t M, int relu, void* stream) {
+  DIGA_CHECK_ARG(slab && running_mean && running_var && weight && bias && scale && shift && raw && out,
+                 "diga_bn_finalize_apply: NULL pointer");
+  DIGA_CHECK_ARG(units_per_sample > 0 && nsamples > 0 && n_a > 0 && n_b >= 0 && M > 0,
+                 "diga_bn_finalize_apply: bad sizes units_per_sample=%d nsamples=%d M=%lld", units_per_sample, nsamples, (long long)M);
+  DIGA_CHECK_ARG(C >= 64 && C <= 2048 && C % 64 == 0, "diga_bn_finalize_apply: C=%d must be a multiple of 64 in [64,2048]", C);
+  DIGA_CHECK_ARG(a_samples >= 0 && a_samples <= nsamples, "diga_bn_finalize_apply: a_samples=%d outside [0,%d]", a_samples, nsamples);
+  DIGA_CHECK_ARG(!per_sample || (n_b == 0 && M % nsamples == 0), "diga_bn_finalize_apply: per_sample statistics: no group B, M a whole number of samples");
+  const int nz = per_sample ? nsamples : 1;
+  const int64_t Ms = M / nz;
+  // ~192 blocks in all (every block repeats the slab reduction of its 64 channels), whole 128-row passes per block
+  int chunks = cdiv(192, (C / 64) * nz);
+  if (chunks > cdiv(Ms, 128)) chunks = cdiv(Ms, 128);
+  const int rpb = cdiv(cdiv(Ms, chunks), 128) * 128;
+  const dim3 grid(C / 64, cdiv(Ms, rpb), nz), block(64 * FIN_PH);
+  hipStream_t st = (hipStream_t)stream;
+  if (!res)
+    hipLaunchKernelGGL(bn_finalize_apply_kernel<0>, grid, block, 0, st, slab, units_per_sample, nsamples, a_samples, per_sample, C, n_a, n_b,
+                       running_mean, running_var, weight, bias, lam, eps, scale, shift, (const u32x4*)raw, (const u32x4*)res, (u32x4*)out, Ms,
+                       relu, rpb);
+  else
+    hipLaunchKernelGGL(bn_finalize_apply_kernel<1>, grid, block, 0, st, slab, units_per_sample, nsamples, a_samples, per_sample, C, n_a, n_b,
+                       running_mean, running_var, weight, bias, lam, eps, scale, shift, (const u32x4*)raw, (const u32x4*)res, (u32x4*)out, Ms,
+                       relu, rpb);
+  DIGA_CHECK_LAUNCH("diga_bn_finalize_apply");
   return DIGA_OK;
 }
 

@@ -146,7 +146,7 @@ class Engine:
     def __init__(self, weights: NetWeights, B: int, H: int, W: int, bn_lambda: float = 0.8, group=None,
                  confidence_threshold: float = 0.9, stream: bool = False, conv_tile: int = 0,
                  autotune: bool = False, fuse_conv3: bool = False, force_exchange: bool = False, fold_finalize: bool = False,
-                 fuse_apply="auto", oneshot: bool = False):
+                 fuse_apply="auto", oneshot: bool = False, fuse_finapply=False):
         """stream=False: x is ONE batch of B samples -> the reference's batch semantics (half_first DAM statistics over
         the batch, prototypes pooled over the batch).  stream=True: x holds B CONSECUTIVE batch-1 frames of a stream
         ("frames in flight"): the trunk runs once over all of them with per-sample DAM statistics (DAM carries no
@@ -181,6 +181,11 @@ class Engine:
             fuse_apply = "conv1" if B * ((H + 7) // 8) * ((W + 7) // 8) >= 4 * 8385 else False
         self.fuse_apply = False if self.fuse_conv3 else ("all" if fuse_apply is True else fuse_apply)
         assert self.fuse_apply in (False, "conv1", "all"), fuse_apply
+        # fuse_finapply: diga_bn_finalize + diga_bn_apply as ONE launch (diga_bn_finalize_apply; bit-identical; not with the
+        # cross-rank exchange, where the sums travel in between).  Built for the one-frame-per-step plan and measured there:
+        # 3.22 vs 3.21-3.24 ms per step (the 9.7 us fused launch replaces 5.1 + 7.0 us of kernel time, but a graph replay does not
+        # get shorter by it), 6.40 vs 5.8-6.1 ms at three frames -- off by default (profiles/experiments/ab_finapply.py).
+        self.fuse_finapply = bool(fuse_finapply)
         # stream + group: the B local samples are this rank's frames of B consecutive GLOBAL batches (one frame per rank
         # per batch): statistics are exchanged per batch, so every global batch keeps the reference's batch semantics
         self.w = weights
@@ -327,6 +332,21 @@ class Engine:
             return sc, sh
         call("diga_bn_finalize", _p(self.slab), ups, self.B, a_samples, 0, bn.C, n_a, n_b, _p(bn.running_mean), _p(bn.running_var),
              _p(bn.weight), _p(bn.bias), lam, 1e-5, _p(sc), _p(sh), _stream())
+        return sc, sh
+
+    def _finapply(self, bn: BNP, ups, rows_per_sample, raw, res, out, M, Cc):
+        """_finalize + _apply (no residual / normalised residual) as one launch -> (scale, shift) of the BN layer."""
+        sc, sh = self._affine(bn)
+        lam = self.lam if bn.lam is None else bn.lam
+        ev = self._aux_start()
+        if self.stream:
+            call("diga_bn_finalize_apply", _p(self.slab), ups, self.B, self.B, 1, bn.C, float(rows_per_sample), 0.0, _p(bn.running_mean),
+                 _p(bn.running_var), _p(bn.weight), _p(bn.bias), lam, 1e-5, _p(sc), _p(sh), _p(raw), _p(res), _p(out), M, 1, _stream())
+        else:
+            split, n_a, n_b = self._groups(rows_per_sample)
+            call("diga_bn_finalize_apply", _p(self.slab), ups, self.B, split // rows_per_sample, 0, bn.C, n_a, n_b, _p(bn.running_mean),
+                 _p(bn.running_var), _p(bn.weight), _p(bn.bias), lam, 1e-5, _p(sc), _p(sh), _p(raw), _p(res), _p(out), M, 1, _stream())
+        self._aux_end(ev, "bn_apply", M * Cc * 2 * (2 if res is None else 3))
         return sc, sh
 
     def _apply(self, raw, sc, sh, res, rsc, rsh, out, M, Cc):
@@ -483,8 +503,10 @@ class Engine:
                 M = B * Ho * Wo
                 rows = Ho * Wo
                 fuse = self.fuse_apply == "all"
+                fa = self.fuse_finapply and not fuse and not self.exchange and not self.fold_finalize and not self.fuse_conv3
                 # conv1 (1x1, carries the stride) -> bn1 -> relu
                 bn1 = w.bn[pre + ".bn1"]
+                pending_was = pending
                 if pending is not None:
                     # the previous block's "bn3 + residual + relu" on this conv's operand path; it writes the block input into nxt
                     psc, psh, ppre = pending
@@ -493,6 +515,8 @@ class Engine:
                     cur, nxt = nxt, cur
                     self._tap(ppre, cur, (B, Hc, Wc, Cc))
                     pending = None
+                elif fa:
+                    nt1 = self._conv(pre + ".conv1", cur, self.raw1, Hc, Wc, Cc, Ho, Wo, pl, s, 1, False, bn1)
                 else:
                     sc, sh = self._conv_bn(pre + ".conv1", cur, self.raw1, Hc, Wc, Cc, Ho, Wo, pl, s, 1, False, bn1)
                 self._tap(pre + ".conv1", self.raw1, (B, Ho, Wo, pl))
@@ -502,9 +526,15 @@ class Engine:
                     sc, sh = self._conv_bn(pre + ".conv2", self.raw1, self.raw2, Ho, Wo, pl, Ho, Wo, pl, 1, dil, True, bn2,
                                            fused_in=(sc, sh, None, None))
                 else:
-                    self._apply(self.raw1, sc, sh, None, None, None, self.act1, M, pl)
+                    if fa and pending_was is None:
+                        self._finapply(bn1, nt1, rows, self.raw1, None, self.act1, M, pl)
+                    else:
+                        self._apply(self.raw1, sc, sh, None, None, None, self.act1, M, pl)
                     self._tap(pre + ".act1", self.act1, (B, Ho, Wo, pl))
-                    sc, sh = self._conv_bn(pre + ".conv2", self.act1, self.raw2, Ho, Wo, pl, Ho, Wo, pl, 1, dil, True, bn2)
+                    if fa:
+                        nt2 = self._conv(pre + ".conv2", self.act1, self.raw2, Ho, Wo, pl, Ho, Wo, pl, 1, dil, True, bn2)
+                    else:
+                        sc, sh = self._conv_bn(pre + ".conv2", self.act1, self.raw2, Ho, Wo, pl, Ho, Wo, pl, 1, dil, True, bn2)
                 self._tap(pre + ".conv2", self.raw2, (B, Ho, Wo, pl))
                 # conv3 (1x1) -> bn3 (+ residual, relu)
                 bn3 = w.bn[pre + ".bn3"]
@@ -518,9 +548,16 @@ class Engine:
                         sc3, sh3 = self._conv_bn(pre + ".conv3", self.raw2, self.raw3, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3,
                                                  fused_in=(sc, sh, None, None))
                     else:
-                        self._apply(self.raw2, sc, sh, None, None, None, self.act2, M, pl)
+                        if fa:
+                            self._finapply(bn2, nt2, rows, self.raw2, None, self.act2, M, pl)
+                        else:
+                            self._apply(self.raw2, sc, sh, None, None, None, self.act2, M, pl)
                         self._tap(pre + ".act2", self.act2, (B, Ho, Wo, pl))
-                        sc3, sh3 = self._conv_bn(pre + ".conv3", self.act2, self.raw3, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)
+                        fa3 = fa and b != 0 and not (self.fuse_apply and b < nb - 1)     # plain "bn3 + residual + relu" follows
+                        if fa3:
+                            nt3 = self._conv(pre + ".conv3", self.act2, self.raw3, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)
+                        else:
+                            sc3, sh3 = self._conv_bn(pre + ".conv3", self.act2, self.raw3, Ho, Wo, pl, Ho, Wo, pl * 4, 1, 1, False, bn3)
                     self._tap(pre + ".conv3", self.raw3, (B, Ho, Wo, pl * 4))
                     if b == 0:    # downsample branch: 1x1 (stride) + bn on the block input
                         bnd = w.bn[pre + ".downsample.1"]
@@ -532,6 +569,8 @@ class Engine:
                         pending = (sc3, sh3, pre)
                         Hc, Wc, Cc = Ho, Wo, pl * 4
                         continue
+                    elif fa and b != 0:
+                        self._finapply(bn3, nt3, rows, self.raw3, cur, nxt, M, pl * 4)
                     else:
                         self._apply(self.raw3, sc3, sh3, cur, None, None, nxt, M, pl * 4)
                 cur, nxt = nxt, cur

@@ -161,6 +161,17 @@ int diga_bn_apply(const void* raw, const float* scale, const float* shift, const
                   const float* res_scale, const float* res_shift, void* out, int64_t M, int C,
                   int relu, int nsamples_affine, void* stream);
 
+/* diga_bn_finalize followed by diga_bn_apply (no residual / normalised residual) in ONE launch (ttda:313-345 +
+ * adaptseg:86-87,90-91,94-100): for small passes (one frame per step), where both kernels sit at their launch floor.
+ * Every block repeats the fixed-order slab reduction of its 64 channels, so scale / shift (also written out, as
+ * diga_bn_finalize does: [C], or [nsamples][C] with per_sample) and `out` are bit-identical to the two-launch form.
+ * M = all rows; per_sample: M is nsamples equal samples, each with its own statistics. */
+int diga_bn_finalize_apply(const float* slab, int units_per_sample, int nsamples, int a_samples,
+                           int per_sample, int C, double n_a, double n_b, const float* running_mean,
+                           const float* running_var, const float* weight, const float* bias, float lam,
+                           float eps, float* scale, float* shift, const void* raw, const void* res, void* out,
+                           int64_t M, int relu, void* stream);
+
 /* The stand-alone module form (SIFABatchNorm2dTrainable.forward on an fp32 NCHW tensor, ttda:299-345):
  * per-channel shifted sums with 64-lane wavefront-shuffle reductions -> slab [2 groups][2][C] for
  * diga_bn_finalize(units_per_sample 1, nsamples 2, a_samples 1) (group A = samples [0, split_b),

@@ -168,6 +168,35 @@ def test_weights_stationary_1x1_is_bit_identical(B, H, W, Cin, Cout):
         call("diga_conv_igemm_bf16", C.byref(d), P(xin), P(w9), P(out), P(slab), P(shift), stream())
 
 
+@pytest.mark.parametrize("B,rows,Cc,per_sample,res", [(1, 8385, 256, 0, False), (1, 1000, 64, 0, True), (3, 545, 128, 1, False),
+                                                      (2, 2145, 1024, 1, True), (4, 300, 512, 0, True), (1, 33153, 64, 0, False)])
+def test_bn_finalize_apply_is_bit_identical(B, rows, Cc, per_sample, res):
+    """diga_bn_finalize_apply == diga_bn_finalize followed by diga_bn_apply: scale, shift and the activation bit for bit
+    (both statistics modes: per-sample, and the half_first groups of a batch)."""
+    g = torch.Generator().manual_seed(rows + Cc + B)
+    ups = (rows + 31) // 32
+    M = B * rows
+    slab = (torch.randn(B * ups * 2 * Cc, generator=g) * 3).abs_().to(DEV)
+    rm, rv, bw, bb = [t.to(DEV) for t in _bn_params(Cc, g)]
+    raw = torch.randn(M * Cc, generator=g).to(torch.bfloat16).to(DEV)
+    r = torch.randn(M * Cc, generator=g).relu().to(torch.bfloat16).to(DEV) if res else None
+    ns = B if per_sample else 1
+    a_samples = B if per_sample else max(1, B // 2)
+    n_a = float(rows if per_sample else a_samples * rows)
+    n_b = 0.0 if per_sample else float((B - a_samples) * rows)
+    sc0, sh0 = torch.empty(ns * Cc, device=DEV), torch.empty(ns * Cc, device=DEV)
+    out0 = torch.empty(M * Cc, dtype=torch.bfloat16, device=DEV)
+    call("diga_bn_finalize", P(slab), ups, B, a_samples, per_sample, Cc, n_a, n_b, P(rm), P(rv), P(bw), P(bb), 0.8, 1e-5, P(sc0), P(sh0), stream())
+    call("diga_bn_apply", P(raw), P(sc0), P(sh0), P(r) if res else None, None, None, P(out0), M, Cc, 1, B if per_sample else 0, stream())
+    sc1, sh1 = torch.full_like(sc0, float("nan")), torch.full_like(sh0, float("nan"))
+    out1 = torch.full((M * Cc,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    call("diga_bn_finalize_apply", P(slab), ups, B, a_samples, per_sample, Cc, n_a, n_b, P(rm), P(rv), P(bw), P(bb), 0.8, 1e-5, P(sc1), P(sh1),
+         P(raw), P(r) if res else None, P(out1), M, 1, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(sc0, sc1) and torch.equal(sh0, sh1)
+    assert torch.equal(out0.view(torch.int16), out1.view(torch.int16))
+
+
 @pytest.mark.parametrize("B,per_sample,tile", [(1, 0, 0), (3, 1, 48), (2, 0, 24), (2, 1, 67)])
 def test_conv3_two_pass_fused_apply(B, per_sample, tile):
     """conv3 -> bn3 -> += residual -> relu as two passes over the GEMM: pass 1 (out = NULL) leaves exactly the slab of the

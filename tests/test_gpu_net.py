@@ -135,6 +135,25 @@ def test_fused_apply_is_bit_identical_to_unfused(weights, B, H, W, stream, mode)
     assert torch.equal(ea.feat.view(torch.int16), eb.feat.view(torch.int16)) and torch.equal(torch.nan_to_num(pa2, nan=-1.0), torch.nan_to_num(pb2, nan=-1.0))
 
 
+@pytest.mark.parametrize("B,H,W,stream", [(1, 129, 257, False), (2, 65, 129, False), (3, 129, 257, True), (1, 512, 1024, False)])
+def test_fused_finalize_apply_is_bit_identical(weights, B, H, W, stream):
+    """Engine(fuse_finapply=True) -- diga_bn_finalize + diga_bn_apply as one launch (the one-frame-per-step plan) -- against the
+    two-launch form: every tap, every scale / shift, features, logits, pseudo labels and the SAM output bit-identical."""
+    ea = Engine(weights, B, H, W, stream=stream, fuse_apply=False, fuse_finapply=True, autotune=False)
+    eb = Engine(weights, B, H, W, stream=stream, fuse_apply=False, fuse_finapply=False, autotune=False)
+    ea.taps, eb.taps = {}, {}
+    xs, ys = zip(*[synth.synth_frame(90 + t, 1, H, W) for t in range(B)])
+    x, y = torch.from_numpy(np.concatenate(xs)).cuda(), torch.from_numpy(np.concatenate(ys)).cuda()
+    pa, pb = ea.forward_and_adapt(x, y, CFG), eb.forward_and_adapt(x, y, CFG)
+    torch.cuda.synchronize()
+    assert set(ea.taps) == set(eb.taps) and len(ea.taps) >= 33 * 6
+    for k in sorted(ea.taps):
+        assert torch.equal(ea.taps[k][0].view(torch.int16), eb.taps[k][0].view(torch.int16)), k
+    assert torch.equal(ea.scale, eb.scale) and torch.equal(ea.shift, eb.shift)
+    assert torch.equal(ea.feat.view(torch.int16), eb.feat.view(torch.int16)) and torch.equal(ea.logits, eb.logits)
+    assert torch.equal(ea.labels, eb.labels) and torch.equal(torch.nan_to_num(pa, nan=-1.0), torch.nan_to_num(pb, nan=-1.0))
+
+
 def _floor():
     import json
     import os
