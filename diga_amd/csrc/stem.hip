@@ -2,11 +2,15 @@
 // Input is the caller's fp32 NCHW frame (BGR, mean-subtracted), output is the raw bf16 NHWC map that
 // bn1+ReLU+maxpool consumes, plus the DAM statistics slab (one unit per block, sample-major: [unit][2][64]).
 //
-// Cin = 3 makes this a 147-deep dot product per output: too thin for the generic 64-channel gather,
-// and only 0.3 % of the frame's FLOPs, so it runs on the fp32 VALU from LDS: a block owns a strip of
-// ROWS output rows x 64 output columns x 64 channels, with the 37 KB weight matrix and the strip's
-// 13 x 133 x 3 input patch in LDS.
+// Cin = 3 makes this a 147-deep dot product per output: too thin for the generic 64-channel gather.  A block owns
+// strips of ROWS output rows x 64 output columns x 64 channels (one statistics unit each), the strip's 13 x 133 x 3
+// input patch in LDS.  Two kernels:
+//  * stem_mfma_kernel (the bf16 product path): fp32 inputs and weights split into bf16 hi + lo, three MFMA terms
+//    (hi.hi + hi.lo + lo.hi: 2^-17 relative per product, well inside the bf16 rounding of the output), weight
+//    fragments resident in registers, persistent blocks;
+//  * stem_kernel<OUT_F32> (the fp32-exact verification mode): fp32 VALU FMAs in the reference's (c, kh, kw) order.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -131,6 +135,184 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
   }
 }
 
+// ---- MFMA form.  GEMM view: out^T[channel][pixel] = W[channel][k] . X[k][pixel] with k = ((c, kh) pair p, kw slot 0..7): the 8
+// k of one lane's fragment are the 8 CONSECUTIVE input columns 2 ow - 3 ... 2 ow + 4 of input row 2 oh - 3 + kh, channel c
+// (slot 7 meets a zero weight), so a pixel fragment is 16 contiguous bytes of the bf16 patch; 21 pairs -> 6 K steps of 4
+// pairs (pairs 21..23 repeat pair 20 against zero weights).  Weights are the A operand, so that a lane's accumulators are
+// consecutive CHANNELS of one pixel: MFMA row m of channel tile T is channel 32 half + 8 (m >> 2) + 4 T + (m & 3), and
+// acc[0][0..3], acc[1][0..3] of lane (g, px) are channels 32 half + 8 g ... + 7 of pixel px: one 16-byte NHWC store.
+// Wave w: channel half w & 1 (weights: 2 tiles x 6 steps x (hi, lo) fragments = 96 registers, loaded once per block),
+// rows 2 (w >> 1), 2 (w >> 1) + 1 of the strip = 8 pixel tiles of 16.
+// sum over the 16 lanes of a DPP row, in every lane of the row, one fixed order: quad neighbours, quad pairs, the mirrored
+// half row, the mirrored row (v_add_f32 with a DPP operand each: no LDS permutes)
+__device__ __forceinline__ float row_sum16(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1, 0, 3, 2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2, 3, 0, 1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  return v;
+}
+
+constexpr int MPW = 160;       // bf16 patch row pitch: 80 words, consecutive rows 16 banks apart (134 used)
+
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                        unsigned short* __restrict__ out, float* __restrict__ slab,
+                                                        const float* __restrict__ shift, int H, int W, int Ho, int Wo,
+                                                        int tiles_w, int tiles_h, int ntiles) {
+  __shared__ __attribute__((aligned(16))) unsigned short sph[3 * PR * MPW];   // hi plane [c][input row][col]
+  __shared__ __attribute__((aligned(16))) unsigned short spl[3 * PR * MPW];   // lo plane
+  __shared__ float sred[2][2][2][32];                                         // [channel half][row half][stat][channel]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chalf = wave & 1, phalf = wave >> 1, g = lane >> 4, px = lane & 15;
+
+  // weight fragments: lane (m = lane & 15, k block g) holds, for step ks, the 7 taps of pair p = 4 ks + g of channel(m, T)
+  bf16x8 wh[2][6], wl[2][6];
+#pragma unroll
+  for (int T = 0; T < 2; ++T) {
+    const int co = chalf * 32 + 8 * (px >> 2) + 4 * T + (px & 3);
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+      const int p = ks * 4 + g;
+      float w[8];
+#pragma unroll
+      for (int kw = 0; kw < 8; ++kw) w[kw] = (p < 21 && kw < 7) ? wgt[co * 147 + p * 7 + kw] : 0.f;
+      u32x4 h, l;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        h[i] = pack_bf16x2(w[2 * i], w[2 * i + 1]);
+        l[i] = pack_bf16x2(w[2 * i] - __uint_as_float(h[i] << 16), w[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+      }
+      wh[T][ks] = __builtin_bit_cast(bf16x8, h);
+      wl[T][ks] = __builtin_bit_cast(bf16x8, l);
+    }
+  }
+  int koff[6];                   // element offset of the lane's (c, kh) row per step
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks) {
+    const int p = min(ks * 4 + g, 20);
+    koff[ks] = ((p / 7) * PR + (p % 7)) * MPW;
+  }
+  float kshift[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) kshift[i] = shift[chalf * 32 + 8 * g + i];
+
+  // patch: a thread owns a PAIR of adjacent columns (one packed conversion, one 4-byte LDS store per plane); a wave owns a
+  // row per pass (its validity is wave-uniform): 10 passes x 4 rows for columns 0 ... 127, one more for columns 128 ... 133.
+  // The loads of the NEXT strip's patch are issued before this strip's MFMA phase and converted / stored after it.
+  constexpr int NPASS = (3 * PR + 3) / 4;
+  f32x2 pv[NPASS + 1];
+  auto patch_load = [&](int strip) {
+    int b = strip;
+    const int tw = b % tiles_w;
+    b /= tiles_w;
+    const int th = b % tiles_h, n = b / tiles_h;
+    const int ow0 = tw * 64, oh0 = th * ROWS;
+    const float* xin = x + (size_t)n * 3 * H * W;
+    const int iwp = ow0 * 2 - 3 + 2 * lane;                     // input column of the pair's first element
+    const bool okc0 = (unsigned)iwp < (unsigned)W, okc1 = (unsigned)(iwp + 1) < (unsigned)W;
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it) {
+      const int cr = it * 4 + wave;                             // wave-uniform
+      const int r = cr % PR, c = cr / PR, ih = oh0 * 2 - 3 + r;
+      pv[it] = f32x2{0.f, 0.f};
+      if (cr < 3 * PR && (unsigned)ih < (unsigned)H) {
+        const float* row = xin + ((size_t)c * H + ih) * W;
+        if (okc0) pv[it][0] = row[iwp];
+        if (okc1) pv[it][1] = row[iwp + 1];
+      }
+    }
+    const int cr = tid / 3, jp = 64 + tid % 3;                  // columns 128 ... 133 as 3 pairs x 39 rows (117 threads)
+    const int r = cr % PR, c = cr / PR, ih = oh0 * 2 - 3 + r, iw = ow0 * 2 - 3 + 2 * jp;
+    pv[NPASS] = f32x2{0.f, 0.f};
+    if (tid < 3 * PR * 3 && (unsigned)ih < (unsigned)H) {
+      const float* row = xin + ((size_t)c * H + ih) * W;
+      if ((unsigned)iw < (unsigned)W) pv[NPASS][0] = row[iw];
+      if (jp < 66 && (unsigned)(iw + 1) < (unsigned)W) pv[NPASS][1] = row[iw + 1];   // column 133 is the zero slot's
+    }
+  };
+  auto put = [&](int cr, int jp, f32x2 v) {
+    const unsigned h = pack_bf16x2(v[0], v[1]);
+    const unsigned l = pack_bf16x2(v[0] - __uint_as_float(h << 16), v[1] - __uint_as_float(h & 0xffff0000u));
+    *reinterpret_cast<unsigned*>(sph + cr * MPW + 2 * jp) = h;
+    *reinterpret_cast<unsigned*>(spl + cr * MPW + 2 * jp) = l;
+  };
+
+  if ((int)blockIdx.x < ntiles) patch_load(blockIdx.x);
+  for (int strip = blockIdx.x; strip < ntiles; strip += gridDim.x) {
+    int b = strip;
+    const int tw = b % tiles_w;
+    b /= tiles_w;
+    const int th = b % tiles_h, n = b / tiles_h;
+    const int ow0 = tw * 64, oh0 = th * ROWS;
+    __syncthreads();             // the previous strip's patch and partial sums have been read
+#pragma unroll
+    for (int it = 0; it < NPASS; ++it)
+      if (it * 4 + wave < 3 * PR) put(it * 4 + wave, lane, pv[it]);
+    if (tid < 3 * PR * 3) put(tid / 3, 64 + tid % 3, pv[NPASS]);
+    __syncthreads();
+    if (strip + (int)gridDim.x < ntiles) patch_load(strip + gridDim.x);
+
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+#pragma unroll 2
+    for (int mt = 0; mt < 8; ++mt) {
+      const int r = phalf * 2 + (mt >> 2), owl = (mt & 3) * 16 + px;
+      const int base = 2 * r * MPW + 2 * owl;
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        const unsigned* ph = reinterpret_cast<const unsigned*>(sph + koff[ks] + base);   // 4-byte aligned: even element offset
+        const unsigned* pl = reinterpret_cast<const unsigned*>(spl + koff[ks] + base);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, (u32x4{ph[0], ph[1], ph[2], ph[3]}));
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, (u32x4{pl[0], pl[1], pl[2], pl[3]}));
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {                 // smallest terms first
+          acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[T][ks], bl, acc[T], 0, 0, 0);
+          acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[T][ks], bh, acc[T], 0, 0, 0);
+          acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[T][ks], bh, acc[T], 0, 0, 0);
+        }
+      }
+      const int oh = oh0 + r, ow = ow0 + owl;
+      if (oh < Ho && ow < Wo) {
+        const float a[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(a[2 * i], a[2 * i + 1]);
+        *reinterpret_cast<u32x4*>(out + (((size_t)n * Ho + oh) * Wo + ow) * 64 + chalf * 32 + 8 * g) = o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float d = a[i] - kshift[i];
+          s1[i] += d;
+          s2[i] = fmaf(d, d, s2[i]);
+        }
+      }
+    }
+    // fold the 16 pixel lanes (fixed butterfly), then the two row halves in a fixed order: deterministic
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s1[i] = row_sum16(s1[i]);
+      s2[i] = row_sum16(s2[i]);
+    }
+    if (px == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        sred[chalf][phalf][0][8 * g + i] = s1[i];
+        sred[chalf][phalf][1][8 * g + i] = s2[i];
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      // statistics unit = this strip: slab[unit][stat][64]; units are numbered sample-major
+      const int stat = tid >> 6, c = tid & 63;
+      slab[((size_t)strip * 2 + stat) * 64 + c] = sred[c >> 5][0][stat][c & 31] + sred[c >> 5][1][stat][c & 31];
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -145,9 +327,9 @@ int stem_launch(const float* x, const float* wgt, void* out, float* stat_slab, c
   if (out_f32)
     hipLaunchKernelGGL(stem_kernel<true>, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, x, wgt, out, stat_slab, stat_shift, H, W, Ho,
                        Wo, tiles_w, tiles_h);
-  else
-    hipLaunchKernelGGL(stem_kernel<false>, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, x, wgt, out, stat_slab, stat_shift, H, W, Ho,
-                       Wo, tiles_w, tiles_h);
+  else   // persistent: two blocks per CU (208 registers), each sets its weight fragments up once for all its strips
+    hipLaunchKernelGGL(stem_mfma_kernel, dim3(ntiles < 512 ? ntiles : 512), dim3(256), 0, (hipStream_t)stream, x, wgt,
+                       static_cast<unsigned short*>(out), stat_slab, stat_shift, H, W, Ho, Wo, tiles_w, tiles_h, ntiles);
   DIGA_CHECK_LAUNCH("diga_stem_conv7x7s2");
   return DIGA_OK;
 }

@@ -12,7 +12,7 @@ from collections import defaultdict
 path, k = sys.argv[1], int(sys.argv[2])
 HBM, MFMA, VALU = 8000.0, 2500.0, 157.3          # GB/s, bf16 TFLOP/s, fp32 vector TFLOP/s (MI355X nominal)
 rows_all = list(csv.DictReader(open(path)))
-stems = sorted(int(r["Start_Timestamp"]) for r in rows_all if "stem_kernel" in r["Kernel_Name"])
+stems = sorted(int(r["Start_Timestamp"]) for r in rows_all if "stem_kernel" in r["Kernel_Name"] or "stem_mfma_kernel" in r["Kernel_Name"])
 SKIP = 8                                          # eager warm-up passes (incl. the tile autotune) + graph warm-up
 t_begin = stems[SKIP]
 dur = defaultdict(float)
@@ -25,6 +25,8 @@ for r in rows_all:
     for plain in ("stem_kernel", "proto_pool_kernel", "proto_dist_kernel", "upsample_argmax_hist_kernel"):      # templated on the storage type since round 2
         if key.startswith(plain + "<"):
             key = plain
+    if key.startswith("stem_mfma_kernel"):        # the bf16 path's stem since the end of round 2 (three bf16 MFMA terms)
+        key = "stem_kernel"
     if key.startswith("conv1x1_ws_kernel"):       # the weights-stationary 1x1 kernel (tile id 91): same work, same row
         key = "conv_igemm_kernel"
     elif key.startswith("conv_igemm_kernel"):
@@ -72,7 +74,8 @@ add("bn_apply_kernel<2>", "hbm", apply2, HBM, "GB/s", "read raw + raw downsample
 add("bn_apply_kernel<0>", "hbm", apply0, HBM, "GB/s", "read raw, write activation")
 add("bn_finalize_kernel", "latency", sum(nb * ((px + 31) // 32) * 2 * 4 * (2 * pl + 4 * pl) for nb, pl, px in L), HBM, "GB/s",
     "104 launches of <= 32 blocks: launch-latency bound, slab bytes shown")
-add("stem_kernel", "valu", 2 * hw1 * 64 * 147, VALU, "TFLOP/s", "7x7 s2 conv, fp32 vector FMA from LDS")
+add("stem_kernel", "hbm", 3 * 512 * 1024 * 4 + hw1 * 64 * 2, HBM, "GB/s",
+    "stem_mfma_kernel: 7x7 s2 conv as three bf16 MFMA terms; read the fp32 frame, write the raw bf16 map (also 2.47 GFLOP x 3 terms per frame)")
 add("bn_relu_maxpool_kernel", "hbm", hw1 * 64 * 2 + hw2 * 64 * 2, HBM, "GB/s", "read stem output, write pooled")
 add("proto_pool_kernel", "hbm", hw3 * 2048 * 2, HBM, "GB/s", "one feature read serves both label sets")
 add("proto_dist_kernel", "valu", 3.0 * hw3 * 38 * 2048, VALU, "TFLOP/s", "sub + fma per (pixel, prototype, channel)")
