@@ -337,17 +337,18 @@ __global__ void proto_flags_frames_kernel(const int32_t* __restrict__ counts, in
 // prototype-distance classifier x2 + blend + softmax fusion (ttda:1707-1709, 1712-1734, 1644)
 // Squared distances are accumulated directly, sum (p - f)^2 in fp32 -- no ||f||^2 - 2 f.p + ||p||^2 expansion
 // (an absolute error in d is a relative error in exp(-d)) -- so this is fp32 VALU work: P x 2C x CH x 2 ops.
-//   1. proto_dist_kernel: block = 64 pixels x 40 prototype slots (slot k < C: instance class k, C <= k < 2C:
-//      running class k-C) x one slice of CH/PCF_SPLIT channels; 128 threads, thread = 4 pixels x 5 slots in
-//      registers: per channel one b128 read of 4 pixel values ([ch][px] image) and one b128 + b32 broadcast read
-//      of 5 prototype values feed 40 VALU ops.  Partial d^2 -> work[split][P][40].
+//   1. proto_dist_kernel: block = 128 pixels x 40 prototype slots (slot k < C: instance class k, C <= k < 2C:
+//      running class k-C) x one slice of CH/PCF_SPLIT channels, 32 channels at a time through LDS; 128 threads,
+//      thread = 8 pixels x 5 slots in registers: per channel two b128 reads of 8 pixel values ([ch][px] image) and one
+//      b128 + b32 broadcast read of 5 prototype values feed 40 packed VALU ops.  Partial d^2 -> work[split][P][40].
 //   2. proto_fuse_kernel: thread = pixel: d^2 = sum of the slices in fixed order, exp(-d), flags, normalise x2,
 //      blends, softmax fusion; 0/0 -> NaN kept.
 // ---------------------------------------------------------------------------------------------
-constexpr int PCF_PIX = 64;
+constexpr int PCF_PIX = 128;
+constexpr int PCF_CHUNK = 32;     // channels per LDS image
 constexpr int PCF_SLOTS = 40;
 constexpr int PCF_SPLIT = 8;
-constexpr int PCF_PITCH = 68;     // floats per channel row of the pixel image (64 + 4: keeps b128 alignment)
+constexpr int PCF_PITCH = 132;    // floats per channel row of the pixel image (128 + 4: keeps b128 alignment)
 
 // prototypes -> protoT[ch][8 slot groups][8] fp32 (5 used per group): the image proto_dist_kernel copies into LDS
 __global__ void proto_transpose_kernel(const float* __restrict__ inst_proto, const float* __restrict__ run_proto,
@@ -372,8 +373,8 @@ template <typename FT>
 __global__ __launch_bounds__(128) void proto_dist_kernel(const FT* __restrict__ feat, const float* __restrict__ protoT,
                                                          float* __restrict__ work, int64_t P, int CH, int ch_per_split, int hw,
                                                          int bps, int64_t proto_set_stride) {
-  __shared__ __attribute__((aligned(16))) float sf[64][PCF_PITCH];   // [ch][px]
-  __shared__ __attribute__((aligned(16))) float spr[64][8][8];       // [ch][slot group][5 used of 8]
+  __shared__ __attribute__((aligned(16))) float sf[PCF_CHUNK][PCF_PITCH];   // [ch][px]
+  __shared__ __attribute__((aligned(16))) float spr[PCF_CHUNK][8][8];       // [ch][slot group][5 used of 8]
   const int tid = threadIdx.x, pg = tid & 15, sg = tid >> 4;
   // blocks never straddle samples (bps blocks per sample), so that every sample can have its own prototypes
   const int smp = blockIdx.x / bps, pix0 = (blockIdx.x - smp * bps) * PCF_PIX;
@@ -381,19 +382,19 @@ __global__ __launch_bounds__(128) void proto_dist_kernel(const FT* __restrict__ 
   protoT += (size_t)smp * proto_set_stride;
   const int chb = blockIdx.y * ch_per_split;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  f32x2 acc[2][5];                       // [pixel pair][prototype]: packed fp32 (v_pk_add_f32 / v_pk_fma_f32)
+  f32x2 acc[4][5];                       // [pixel pair][prototype]: packed fp32 (v_pk_add_f32 / v_pk_fma_f32)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int k = 0; k < 5; ++k) acc[i][k] = f32x2{0.f, 0.f};
   // the next chunk's global data (4 feature octets + 8 prototype float4 per thread) is fetched into registers while
   // the current chunk is being reduced, so its latency is off the critical path
   float fr[4][8];
-  f32x4 pr[8];
+  f32x4 pr[4];
   auto fetch = [&](int ch0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {            // feature tile: 64 px x 8 octets, 4 per thread; 8 lanes read one row's 64 channels
-      const int id = tid + 128 * j, r = id >> 3, o = id & 7;
+    for (int j = 0; j < 4; ++j) {            // feature tile: 128 px x 4 octets, 4 per thread; 4 lanes read one row's 32 channels
+      const int id = tid + 128 * j, r = id >> 2, o = id & 3;
       if (pix0 + r < hw) {
         load_row8(feat + (size_t)(p0 + r) * CH + ch0 + o * 8, fr[j]);
       } else {
@@ -401,47 +402,50 @@ __global__ __launch_bounds__(128) void proto_dist_kernel(const FT* __restrict__ 
         for (int i = 0; i < 8; ++i) fr[j][i] = 0.f;
       }
     }
-    const f32x4* src = reinterpret_cast<const f32x4*>(protoT + (size_t)ch0 * 64);   // prototype image: straight 16 KB copy
+    const f32x4* src = reinterpret_cast<const f32x4*>(protoT + (size_t)ch0 * 64);   // prototype image: straight 8 KB copy
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pr[j] = src[tid + 128 * j];
+    for (int j = 0; j < 4; ++j) pr[j] = src[tid + 128 * j];
   };
   fetch(chb);
-  for (int ch0 = chb; ch0 < chb + ch_per_split; ch0 += 64) {
+  for (int ch0 = chb; ch0 < chb + ch_per_split; ch0 += PCF_CHUNK) {
     __syncthreads();                           // everyone is done reading the previous chunk's LDS image
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int id = tid + 128 * j, r = id >> 3, o = id & 7;
+      const int id = tid + 128 * j, r = id >> 2, o = id & 3;
 #pragma unroll
       for (int i = 0; i < 8; ++i) sf[o * 8 + i][r] = fr[j][i];
     }
     {
       f32x4* dst = reinterpret_cast<f32x4*>(&spr[0][0][0]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dst[tid + 128 * j] = pr[j];
+      for (int j = 0; j < 4; ++j) dst[tid + 128 * j] = pr[j];
     }
     __syncthreads();
-    if (ch0 + 64 < chb + ch_per_split) fetch(ch0 + 64);
+    if (ch0 + PCF_CHUNK < chb + ch_per_split) fetch(ch0 + PCF_CHUNK);
 #pragma unroll 4
-    for (int ch = 0; ch < 64; ++ch) {
-      const f32x4 f = *reinterpret_cast<const f32x4*>(&sf[ch][pg * 4]);
+    for (int ch = 0; ch < PCF_CHUNK; ++ch) {
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(&sf[ch][pg * 8]);
+      const f32x4 fb = *reinterpret_cast<const f32x4*>(&sf[ch][pg * 8 + 4]);
       const f32x4 q = *reinterpret_cast<const f32x4*>(&spr[ch][sg][0]);
       const float q4 = spr[ch][sg][4];
-      const f32x2 f01 = f32x2{f[0], f[1]}, f23 = f32x2{f[2], f[3]};
+      const f32x2 fp[4] = {f32x2{fa[0], fa[1]}, f32x2{fa[2], fa[3]}, f32x2{fb[0], fb[1]}, f32x2{fb[2], fb[3]}};
       const float qq[5] = {q[0], q[1], q[2], q[3], q4};
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
         const f32x2 qk = f32x2{qq[k], qq[k]};
-        const f32x2 d0 = qk - f01, d1 = qk - f23;
-        acc[0][k] = __builtin_elementwise_fma(d0, d0, acc[0][k]);
-        acc[1][k] = __builtin_elementwise_fma(d1, d1, acc[1][k]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x2 d = qk - fp[i];
+          acc[i][k] = __builtin_elementwise_fma(d, d, acc[i][k]);
+        }
       }
     }
   }
   float* w = work + (size_t)blockIdx.y * P * PCF_SLOTS;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t p = p0 + pg * 4 + i;
-    if (pix0 + pg * 4 + i < hw) {
+  for (int i = 0; i < 8; ++i) {
+    const int64_t p = p0 + pg * 8 + i;
+    if (pix0 + pg * 8 + i < hw) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) w[p * PCF_SLOTS + sg * 5 + k] = acc[i >> 1][k][i & 1];
     }
