@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void head_finish_pl_kernel(const float* __rest
 // head as ONE dense GEMM + tap gather (adaptseg:119-121): z[m][t*C + c] = feat[m] . W_t[c] for the 18 taps of the two
 // executed branches is a plain 1x1 igemm (the feature map is read once instead of 18 times); the 3x3 dilated
 // convolutions are then logits[m][c] = bias[c] + sum_t z[m + shift_t][t*C + c] over the taps that land inside the
-// image (zero padding).  Block = 8 pixels x 32 lanes (lane = class): every tap is one contiguous 76-byte read per pixel.
+// image (zero padding).  32 lanes per pixel (lane = class): every tap is one contiguous 76-byte read per pixel.
 // The label rule is the one of head_finish_pl_kernel (same arithmetic order).
 // ---------------------------------------------------------------------------------------------
 struct TapList {
@@ -56,38 +56,64 @@ struct TapList {
   short dy[DIGA_MAX_TAPS], dx[DIGA_MAX_TAPS];
 };
 
+constexpr int HTS_PX = 64;      // pixels per block
+
+// Block = 64 pixels.  Phase 1: 8 groups of 32 lanes (lane = class) take 8 pixels each; the tap reads of a pixel are issued in
+// batches of 6 before they are summed (in tap order: the arithmetic of the one-pixel-per-group form), sums -> LDS.  Phase 2: the
+// logits are written with the PIXEL as the fast index (NCHW planes: 256-byte runs instead of 4-byte scatters).  Phase 3: one thread
+// per pixel applies the label rule.
 __global__ __launch_bounds__(256) void head_tapsum_pl_kernel(const float* __restrict__ z, int zstride, const TapList taps,
                                                              const float* __restrict__ bias, float* __restrict__ logits_out,
                                                              int32_t* __restrict__ labels, int64_t P, int C, int h, int w, float thr,
                                                              int64_t lstride) {
-  __shared__ float sl[8][32];
+  __shared__ float sl[HTS_PX][33];
   const int lane = threadIdx.x & 31, pp = threadIdx.x >> 5;
-  const int64_t p = (int64_t)blockIdx.x * 8 + pp;
+  const int64_t p0 = (int64_t)blockIdx.x * HTS_PX;
   const int hw = h * w;
-  const bool live = p < P;
-  int64_t b = 0;
-  int pix = 0;
-  if (live) {
-    b = p / hw;
-    pix = (int)(p - b * hw);
-    const int oh = pix / w, ow = pix - oh * w;
-    float acc = lane < C ? bias[lane] : 0.f;
-    if (lane < C) {
-      for (int t = 0; t < taps.n; ++t) {
-        const int ih = oh + taps.dy[t], iw = ow + taps.dx[t];
-        if ((unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w)
-          acc += z[(size_t)(b * hw + ih * w + iw) * zstride + t * C + lane];
+  const float bv = lane < C ? bias[lane] : 0.f;
+  for (int g = 0; g < HTS_PX / 8; ++g) {
+    const int lp = g * 8 + pp;
+    const int64_t p = p0 + lp;
+    float acc = bv;
+    if (p < P && lane < C) {
+      const int64_t b = p / hw;
+      const int pix = (int)(p - b * hw);
+      const int oh = pix / w, ow = pix - oh * w;
+      const float* zb = z + (size_t)(b * hw) * zstride + lane;
+#pragma unroll
+      for (int t0 = 0; t0 < DIGA_MAX_TAPS; t0 += 6) {
+        float v[6];
+        bool ok[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int t = t0 + j;
+          const int ih = oh + taps.dy[t], iw = ow + taps.dx[t];
+          ok[j] = t < taps.n && (unsigned)ih < (unsigned)h && (unsigned)iw < (unsigned)w;
+          v[j] = ok[j] ? zb[(size_t)(ih * w + iw) * zstride + t * C] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (ok[j]) acc += v[j];
       }
-      logits_out[((size_t)b * C + lane) * hw + pix] = acc;
     }
-    sl[pp][lane] = acc;
+    sl[lp][lane] = acc;
   }
   __syncthreads();
-  if (!live || lane != 0) return;
-  float mx = sl[pp][0];
+  for (int e = threadIdx.x; e < HTS_PX * C; e += 256) {
+    const int c = e / HTS_PX, lp = e - c * HTS_PX;
+    const int64_t p = p0 + lp;
+    if (p < P) {
+      const int64_t b = p / hw;
+      logits_out[((size_t)b * C + c) * hw + (p - b * hw)] = sl[lp][c];
+    }
+  }
+  const int64_t p = p0 + threadIdx.x;
+  if (threadIdx.x >= HTS_PX || p >= P) return;
+  const float* l = sl[threadIdx.x];
+  float mx = l[0];
   int am = 0;
   for (int c = 1; c < C; ++c) {
-    const float v = sl[pp][c];
+    const float v = l[c];
     const bool better = (v > mx) || (v != v && mx == mx);
     if (better) {
       mx = v;
@@ -95,9 +121,10 @@ __global__ __launch_bounds__(256) void head_tapsum_pl_kernel(const float* __rest
     }
   }
   float sum = 0.f;
-  for (int c = 0; c < C; ++c) sum += expf(sl[pp][c] - mx);
+  for (int c = 0; c < C; ++c) sum += expf(l[c] - mx);
   const float pmax = 1.0f / sum;
-  labels[b * lstride + pix] = (pmax < thr) ? 255 : am;
+  const int64_t b = p / hw;
+  labels[b * lstride + (p - b * hw)] = (pmax < thr) ? 255 : am;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -530,7 +557,7 @@ extern "C" int diga_head_tapsum_pseudo_label(const float* z, int zstride, int nt
     tl.dx[t] = t < ntaps ? dx_host[t] : 0;
   }
   const int64_t P = (int64_t)B * h * w;
-  hipLaunchKernelGGL(head_tapsum_pl_kernel, dim3(cdiv(P, 8)), dim3(256), 0, (hipStream_t)stream, z, zstride, tl, bias_sum, logits_out,
+  hipLaunchKernelGGL(head_tapsum_pl_kernel, dim3(cdiv(P, HTS_PX)), dim3(256), 0, (hipStream_t)stream, z, zstride, tl, bias_sum, logits_out,
                      labels, P, C, h, w, threshold, label_sample_stride ? label_sample_stride : (int64_t)h * w);
   DIGA_CHECK_LAUNCH("diga_head_tapsum_pseudo_label");
   return DIGA_OK;
