@@ -11,4 +11,4 @@ if [ -n "$2" ]; then
 else
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 bench.py $Q > $O/trace.log 2>&1
 fi
-python3 profiles/kernel_roofline.py $O/trace/t_kernel_trace.csv 15 | grep -E "stem_kernel|proto_dist|head_tapsum|bn_apply|All kernels|conv_igemm"
+python3 profiles/kernel_roofline.py $O/trace/t_kernel_trace.csv 15 | grep -E "stem_kernel|proto_dist|head_tapsum|All kernels|conv_igemm"
