@@ -113,7 +113,11 @@ int diga_conv_igemm_bf16_apply(const diga_conv_desc* desc, const void* in, const
 
 /* Stem (adaptseg:133,178): 7x7 stride 2 pad 3, 3 -> 64, fp32 NCHW input [B,3,H,W] -> raw bf16 NHWC
  * [B,Ho,Wo,64] + statistics slab [units][2][64] (sample-major, units/B per sample).
- * wgt: fp32 [64][3][7][7] (the reference layout).  Returns the number of slab units when x == NULL. */
+ * wgt: fp32 [64][3][7][7] (the reference layout).  Returns the number of slab units when x == NULL.
+ * Arithmetic: inputs and weights are split into bf16 hi + lo and multiplied on the matrix pipes in three terms
+ * (hi.lo + lo.hi + hi.hi, fp32 accumulation: 2^-17 relative per product, far inside the bf16 rounding of the output;
+ * diga_stem_conv7x7s2_f32 below is the fp32 vector form in the reference's (c, kh, kw) order).  x must be finite and
+ * below bf16's range (an image is): the K padding of the matrix form multiplies neighbouring pixels by zero weights. */
 int diga_stem_conv7x7s2(const float* x, const float* wgt, void* out, float* stat_slab,
                         const float* stat_shift, int B, int H, int W, void* stream);
 
