@@ -212,6 +212,42 @@ def test_tail_fixture(gold_tail):
         assert np.array_equal(hist.cpu().numpy().reshape(C_, C_), g["tail_hist2"].astype(np.int64))
 
 
+@pytest.mark.parametrize("B,h,w,H,W", [(3, 23, 37, 181, 300), (2, 65, 129, 512, 1024), (1, 9, 5, 11, 7), (2, 6, 40, 45, 317)])
+def test_tail_ragged_sizes_against_torch(B, h, w, H, W):
+    """The tail at sizes that are no multiple of its 8 x 128 output tiles (and one small scale factor, which takes the untiled
+    kernel): up-sampled probabilities against torch's bilinear interpolation (align_corners=False, as nn.Upsample in ttda:1610),
+    arg-max bit-exact outside a 1e-6 top-2 margin, histogram equal to a numpy bincount of (target, arg-max)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    probs = torch.rand(B, NC, h, w, generator=g).softmax(1).contiguous()
+    tgt = torch.randint(0, NC + 2, (B, H, W), generator=g)
+    tgt[tgt >= NC] = 255
+    ref = F.interpolate(probs, size=(H, W), mode="bilinear", align_corners=False)
+    pd, td = probs.to(DEV), tgt.to(DEV)
+    pred = torch.empty(B, H, W, dtype=torch.uint8, device=DEV)
+    hist = torch.zeros(NC * NC, dtype=torch.int64, device=DEV)
+    up = torch.empty(B, NC, H, W, dtype=torch.float32, device=DEV)
+    call("diga_upsample_argmax_hist_frames", P(pd), P(td), 1, P(pred), P(hist), P(up), B, NC, h, w, H, W, stream())
+    torch.cuda.synchronize()
+    assert (up.cpu() - ref).abs().max().item() < 1e-6
+    srt = ref.sort(1)[0]
+    safe = (srt[:, -1] - srt[:, -2] > 1e-6).numpy()
+    assert safe.mean() > 0.999
+    got = pred.cpu().numpy()
+    assert np.array_equal(got[safe], ref.argmax(1).numpy()[safe])
+    # the histogram counts the kernel's own arg-max: one entry per labelled pixel
+    t = tgt.numpy().reshape(-1)
+    m = t < NC
+    want = np.bincount(t[m] * NC + got.reshape(-1)[m].astype(np.int64), minlength=NC * NC)
+    assert np.array_equal(hist.cpu().numpy(), want)
+    # without the probability output and with int32 targets: same counts
+    hist2 = torch.zeros_like(hist)
+    t32 = td.to(torch.int32)
+    call("diga_upsample_argmax_hist_frames", P(pd), P(t32), 0, None, P(hist2), None, B, NC, h, w, H, W, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(hist, hist2)
+
+
 def test_frames_in_flight_entry_points_equal_per_frame_calls(gold_sam):
     """diga_proto_pool_frames / diga_proto_update_frames / diga_proto_classify_fuse_frames / diga_upsample_argmax_hist_frames
     on the 3-frame reference sequence (B = 1) in ONE launch set: bit-identical to the per-frame calls, and therefore equal
