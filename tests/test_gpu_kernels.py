@@ -321,7 +321,7 @@ def test_head_as_gemm_plus_tap_gather(B, h, w):
     assert np.array_equal(labels.cpu().numpy()[safe], want[safe]) and (~safe).sum() <= 2
 
 
-@pytest.mark.parametrize("B,H,W", [(1, 65, 129), (2, 47, 35), (1, 129, 257)])
+@pytest.mark.parametrize("B,H,W", [(1, 65, 129), (2, 47, 35), (1, 129, 257), (3, 260, 1030)])   # the last: 891 strips for 512 persistent blocks
 def test_stem_bn_maxpool(B, H, W):
     g = torch.Generator().manual_seed(H)
     x = (torch.randn(B, 3, H, W, generator=g) * 50).clamp(-123, 151)
