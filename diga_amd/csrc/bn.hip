@@ -458,7 +458,9 @@ extern "C" int diga_bn_apply(const void* raw, const float* scale, const float* s
   // Rows per thread: 2 (4 for narrow tensors).  Many small blocks in flight beat long per-thread row walks -- same-box sweep at
   // 15 frames (profiles/experiments/bench_apply.py): C = 256: 23.7 -> 21.3 us, C = 1024 + residual: 129.8 -> 113.1 us (6.8 TB/s of
   // algorithmic bytes), C = 2048 + residual: 316 -> 261 us -- but not one row (the thread's 16 scale / shift words are loaded per block)
-  int rpb = (C8 <= 16 ? 4 : 2) * rstep;
+  // the downsample form loads a second scale / shift set per block: four rows per thread there (619 -> 567 us over its four
+  // launches at 15 frames; eight rows: the same)
+  int rpb = (C8 <= 16 || res_scale ? 4 : 2) * rstep;
   if (cdiv(Ms, rpb) > 65535) rpb = cdiv(cdiv(Ms, 65535), rstep) * rstep;
   const dim3 grid(cdiv(Ms, rpb), ns), block(256);
   hipStream_t st = (hipStream_t)stream;
