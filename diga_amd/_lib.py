@@ -75,6 +75,8 @@ SIGNATURES = {
     "diga_xgmi_destroy": (_i, [_vp]),
     "diga_xgmi_allreduce": (_i, [_vp, _vp, _i64, _i, _vp]),
     "diga_xgmi_check": (_i, [_vp]),
+    "diga_xgmi_set_timeout_ms": (_i, [_vp, _i]),
+    "diga_bn_exchange_finalize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
     "diga_preprocess_image": (_i, [_vp, _i, _vp, _i, _i, _i, _d, _d, _d, _i, _vp]),
     "diga_map_labels": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _vp]),
     "diga_stem_conv7x7s2_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

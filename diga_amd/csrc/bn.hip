@@ -13,27 +13,6 @@ namespace {
 // u0+w, u0+w+FIN_PH, ... of a unit range in fp64; the phases are then combined through LDS in fixed order
 // -> deterministic, and a sample's result does not depend on which batch it is part of (dam_affine.h).
 
-// sums of group A (units [a0,a1)) and group B (units [a1,b1)) -> s[4] valid in phase 0 of the block
-__device__ __forceinline__ void slab_group_sums(const float* __restrict__ slab, int a0, int a1, int b1, int C, int c, bool live,
-                                                double (*red)[4][64], double* s) {
-  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  s[0] = s[1] = s[2] = s[3] = 0;
-  if (live) {
-    slab_range_sums(slab, a0, a1, C, c, ph, s);
-    slab_range_sums(slab, a1, b1, C, c, ph, s + 2);
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) red[ph][k][lane] = s[k];
-  __syncthreads();
-  if (ph != 0) return;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    double v = 0;
-    for (int w = 0; w < FIN_PH; ++w) v += red[w][k][lane];
-    s[k] = v;
-  }
-}
-
 __global__ __launch_bounds__(64 * FIN_PH) void bn_finalize_kernel(const float* __restrict__ slab, int ups, int nsamples, int a_samples,
                                                                  int per_sample, int C, double n_a, double n_b,
                                                                  const float* __restrict__ rmean, const float* __restrict__ rvar,

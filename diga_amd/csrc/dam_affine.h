@@ -26,6 +26,27 @@ __device__ __forceinline__ void slab_range_sums(const float* __restrict__ slab, 
   }
 }
 
+// sums of group A (units [a0,a1)) and group B (units [a1,b1)) -> s[4] valid in phase 0 of the block
+__device__ __forceinline__ void slab_group_sums(const float* __restrict__ slab, int a0, int a1, int b1, int C, int c, bool live,
+                                                double (*red)[4][64], double* s) {
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  s[0] = s[1] = s[2] = s[3] = 0;
+  if (live) {
+    slab_range_sums(slab, a0, a1, C, c, ph, s);
+    slab_range_sums(slab, a1, b1, C, c, ph, s + 2);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[ph][k][lane] = s[k];
+  __syncthreads();
+  if (ph != 0) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double v = 0;
+    for (int w = 0; w < FIN_PH; ++w) v += red[w][k][lane];
+    s[k] = v;
+  }
+}
+
 // group sums (fp64) -> lambda-mixed scale/shift of channel c  (ttda:313-343)
 __device__ __forceinline__ void dam_affine_from_sums(const double* s, int c, double n_a, double n_b, const float* __restrict__ rmean,
                                                      const float* __restrict__ rvar, const float* __restrict__ weight,

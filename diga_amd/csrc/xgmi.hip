@@ -10,6 +10,7 @@
 // nor the reader's L2 can hold them back or serve stale lines.  Waiting is a BOUNDED spin: a peer that never arrives makes the
 // call fail (error word, DIGA_ELAUNCH from diga_xgmi_check) instead of hanging the GPU.
 #include "common.h"
+#include "dam_affine.h"
 #include <string.h>
 
 namespace {
@@ -17,19 +18,43 @@ namespace {
 constexpr int XG_MAX_WORLD = 8;
 constexpr int XG_MAX_BLOCKS = 512;            // blocks of one launch (each owns XG_EPB elements and its own flag / epoch)
 constexpr int XG_EPB = 2048;                  // 8-byte elements per block
-constexpr unsigned XG_SPIN_LIMIT = 1u << 22;  // polls of ~1 us each (sleep + a system-scope load): a few seconds, then give up
+constexpr long long XG_TICKS_PER_MS = 100000;  // wall_clock64() counts a constant 100 MHz clock (s_memrealtime)
+constexpr int XG_DEFAULT_TIMEOUT_MS = 30000;   // bounded wait: a peer that has not arrived after this long is an error, not a hang
+// region B: the exchange fused into the DAM finalize (bn_exchange_finalize_kernel): its own slots, flags, epochs and tickets, so
+// that its (channel block, set) element mapping never meets the plain all-reduce's (block, 2048 elements) mapping on one parity
+constexpr int XB_MAX_X = 32;                   // 64-channel blocks (C <= 2048)
+constexpr int XB_MAX_SETS = 16;                // statistics sets (global batches in flight) per launch
+constexpr long long XB_SLOT_ELEMS = (long long)XB_MAX_X * XB_MAX_SETS * 4 * 64;
 
 struct XgDev {                                // passed to the kernel by value
   unsigned char* peer[XG_MAX_WORLD];          // every rank's buffer as mapped in THIS process (peer[rank] = the local one)
   int world, rank;
   long long max_elems;                        // 8-byte elements per slot
+  long long timeout_ticks;                    // bound of every wait, in wall_clock64() ticks
 };
 
-// buffer layout (bytes): [2 parities][world][max_elems] x 8 | flags [world][XG_MAX_BLOCKS] u32 | epoch [XG_MAX_BLOCKS] u32 | error u32
+// buffer layout (bytes): [2 parities][world][max_elems] x 8 | flags [world][XG_MAX_BLOCKS] u32 | epoch [XG_MAX_BLOCKS] u32 |
+//   region B: [2 parities][world][XB_SLOT_ELEMS] x 8 | flagsB [world][XB_MAX_X] u32 | epochB [XB_MAX_X] u32 | ticketB [XB_MAX_X] u32 | error u32
 __host__ __device__ inline size_t xg_slot_off(const XgDev& d, int parity, int r) { return ((size_t)parity * d.world + r) * d.max_elems * 8; }
 __host__ __device__ inline size_t xg_flags_off(const XgDev& d) { return (size_t)2 * d.world * d.max_elems * 8; }
 __host__ __device__ inline size_t xg_epoch_off(const XgDev& d) { return xg_flags_off(d) + (size_t)d.world * XG_MAX_BLOCKS * 4; }
-__host__ __device__ inline size_t xg_error_off(const XgDev& d) { return xg_epoch_off(d) + (size_t)XG_MAX_BLOCKS * 4; }
+__host__ __device__ inline size_t xb_slot_off(const XgDev& d, int parity, int r) {
+  return xg_epoch_off(d) + (size_t)XG_MAX_BLOCKS * 4 + ((size_t)parity * d.world + r) * XB_SLOT_ELEMS * 8;
+}
+__host__ __device__ inline size_t xb_flags_off(const XgDev& d) { return xb_slot_off(d, 2, 0); }
+__host__ __device__ inline size_t xb_epoch_off(const XgDev& d) { return xb_flags_off(d) + (size_t)d.world * XB_MAX_X * 4; }
+__host__ __device__ inline size_t xb_ticket_off(const XgDev& d) { return xb_epoch_off(d) + (size_t)XB_MAX_X * 4; }
+__host__ __device__ inline size_t xg_error_off(const XgDev& d) { return xb_ticket_off(d) + (size_t)XB_MAX_X * 4; }
+
+// bounded wait until *flag has reached sequence number e (system-scope acquire loads; ~1 us per poll); false = timed out
+__device__ __forceinline__ bool xg_wait_flag(const unsigned* flag, unsigned e, long long timeout_ticks) {
+  const long long t0 = wall_clock64();
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > timeout_ticks) return false;
+  }
+  return true;
+}
 __host__ __device__ inline size_t xg_total_bytes(const XgDev& d) { return (xg_error_off(d) + 4 + 255) / 256 * 256; }
 
 template <typename T>
@@ -65,18 +90,16 @@ __global__ __launch_bounds__(256) void xgmi_allreduce_kernel(const XgDev d, unsi
     __hip_atomic_store(f, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // 2. wait until every rank's contribution to this block has landed in MY buffer (bounded)
     const unsigned* mine = reinterpret_cast<const unsigned*>(me + xg_flags_off(d)) + (size_t)tid * XG_MAX_BLOCKS + b;
-    unsigned spins = 0;
-    while ((int)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > XG_SPIN_LIMIT) {
-        s_fail = 1;
-        break;
-      }
-    }
+    if (!xg_wait_flag(mine, e, d.timeout_ticks)) s_fail = 1;
   }
   __syncthreads();
-  if (s_fail) {                                           // a peer never arrived: report, leave data untouched, do not hang
+  if (s_fail) {
+    // a peer never arrived: do not hang; set the sticky error word (diga_xgmi_check) and POISON the payload -- NaN for the
+    // floating-point types, INT32_MIN for counts -- so that the failure travels with the data instead of leaving plausible
+    // un-reduced local sums behind
     if (tid == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(me + xg_error_off(d)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long poison = DT == 0 ? 0x7ff8000000000000ull : DT == 1 ? 0x7fc000007fc00000ull : 0x8000000080000000ull;
+    for (long long i = lo + tid; i < hi; i += 256) data[i] = poison;
   } else {
     // 3. sum the slots in rank order (the same order on every rank: identical bits everywhere)
     for (long long i = lo + tid; i < hi; i += 256) {
@@ -113,6 +136,87 @@ __global__ __launch_bounds__(256) void xgmi_allreduce_kernel(const XgDev d, unsi
   if (tid == 0) epoch[b] = e;
 }
 
+// The exchange FUSED into the DAM finalize: ONE launch per BN layer does what diga_bn_reduce_slab +
+// diga_xgmi_allreduce + diga_bn_finalize_sums do in three.  Grid (C / 64, nsets), block = 64 channels x FIN_PH unit phases.
+//   1. every block reduces its (channel block x, set) of the local slab in the fixed order of diga_bn_finalize (dam_affine.h);
+//   2. its wave 0 writes the 4 x 64 fp64 group sums into slot [parity][rank] of EVERY rank's buffer (one hop over the direct
+//      link), fences, and takes a ticket of channel block x;
+//   3. the LAST of the nsets blocks of x (all of this rank's sums of x have landed everywhere) raises flag [rank][x] on every
+//      peer, waits -- bounded -- for the peers' flags on its own buffer, sums the slots in RANK ORDER (identical bits on every
+//      rank, and the bits of diga_xgmi_allreduce) and turns them into scale / shift [nsets][C] with dam_affine_from_sums.
+// Only C / 64 <= 32 blocks of a launch ever wait for a peer, so two communicators in flight on two HIP streams (two windows)
+// cannot starve each other's convolutions of CUs: every other block has finished once its sums are written.
+// Time-out: scale / shift of the channel block are set to NaN and the sticky error word is raised.
+__global__ __launch_bounds__(64 * FIN_PH) void bn_exchange_finalize_kernel(const XgDev d, const float* __restrict__ slab, int ups,
+                                                                          int nsamples, int a_samples, int per_sample, int C, double n_a,
+                                                                          double n_b, const float* __restrict__ rmean,
+                                                                          const float* __restrict__ rvar, const float* __restrict__ weight,
+                                                                          const float* __restrict__ bias, float lam, float eps,
+                                                                          float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double red[FIN_PH][4][64];
+  __shared__ int s_last, s_fail;
+  const int tid = threadIdx.x, lane = tid & 63, ph = tid >> 6;
+  const int x = blockIdx.x, set = blockIdx.y, nsets = gridDim.y;
+  const int c = x * 64 + lane;
+  unsigned char* const me = d.peer[d.rank];
+  unsigned* const epoch = reinterpret_cast<unsigned*>(me + xb_epoch_off(d)) + x;
+  unsigned* const ticket = reinterpret_cast<unsigned*>(me + xb_ticket_off(d)) + x;
+  const unsigned e = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;     // the same on every rank
+  const int parity = (int)(e & 1u);
+  if (tid == 0) s_last = 0, s_fail = 0;
+  double s[4];
+  if (per_sample) {     // set = local sample = this rank's frame of global batch `set`: all of it is group A (rank 0) or group B
+    const int u0 = set * ups, u1 = u0 + ups;
+    slab_group_sums(slab, u0, a_samples > 0 ? u1 : u0, u1, C, c, c < C, red, s);
+  } else {
+    slab_group_sums(slab, 0, a_samples * ups, nsamples * ups, C, c, c < C, red, s);
+  }
+  const size_t elem0 = ((size_t)(x * XB_MAX_SETS + set) * 4) * 64 + lane;
+  if (ph == 0) {
+    for (int r = 0; r < d.world; ++r) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(d.peer[r] + xb_slot_off(d, parity, d.rank)) + elem0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) __hip_atomic_store(dst + k * 64, Acc<double>::to_bits(s[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+  }
+  __syncthreads();
+  if (tid == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM) == (unsigned)(nsets - 1);
+  __syncthreads();
+  if (!s_last) return;
+  if (tid < d.world) {
+    unsigned* f = reinterpret_cast<unsigned*>(d.peer[tid] + xb_flags_off(d)) + (size_t)d.rank * XB_MAX_X + x;
+    __hip_atomic_store(f, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned* mine = reinterpret_cast<const unsigned*>(me + xb_flags_off(d)) + (size_t)tid * XB_MAX_X + x;
+    if (!xg_wait_flag(mine, e, d.timeout_ticks)) s_fail = 1;
+  }
+  __syncthreads();
+  if (ph < nsets && c < C) {          // thread = (set ph, channel lane)
+    float* sc = scale + (size_t)ph * C;
+    float* sh = shift + (size_t)ph * C;
+    if (s_fail) {
+      sc[c] = sh[c] = __uint_as_float(0x7fc00000u);
+    } else {
+      const size_t el = ((size_t)(x * XB_MAX_SETS + ph) * 4) * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double v = 0.0;
+        for (int r = 0; r < d.world; ++r)
+          v += Acc<double>::from_bits(__hip_atomic_load(reinterpret_cast<const unsigned long long*>(me + xb_slot_off(d, parity, r)) + el + k * 64,
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        s[k] = v;
+      }
+      dam_affine_from_sums(s, c, n_a, n_b, rmean, rvar, weight, bias, lam, eps, sc, sh);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (s_fail) __hip_atomic_store(reinterpret_cast<unsigned*>(me + xg_error_off(d)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 struct XgComm {
   XgDev dev;
   bool connected = false;
@@ -136,6 +240,7 @@ extern "C" int diga_xgmi_create(int world, int rank, int64_t max_elems, void** c
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
   XgComm* c = new XgComm();
   c->dev.world = world, c->dev.rank = rank, c->dev.max_elems = max_elems;
+  c->dev.timeout_ticks = (long long)XG_DEFAULT_TIMEOUT_MS * XG_TICKS_PER_MS;
   void* buf = nullptr;
   // set-up time: the exchange itself never allocates.  Uncached (fine-grained) device memory, as RCCL uses for its own peer
   // buffers: remote writes and local reads do not depend on L2 write-back / invalidation; plain device memory as a fallback.
@@ -221,8 +326,36 @@ extern "C" int diga_xgmi_check(void* comm) {
     return DIGA_ELAUNCH;
   }
   if (err) {
-    diga_set_error("diga_xgmi_allreduce: a peer's contribution never arrived (bounded wait expired)");
+    diga_set_error("one-shot exchange: a peer's contribution never arrived (bounded wait expired); the payload was poisoned (NaN / INT32_MIN) "
+                   "and the communicator must not be used again");
     return DIGA_ELAUNCH;
   }
+  return DIGA_OK;
+}
+
+extern "C" int diga_xgmi_set_timeout_ms(void* comm, int timeout_ms) {
+  XgComm* c = (XgComm*)comm;
+  DIGA_CHECK_ARG(c != nullptr && timeout_ms >= 1 && timeout_ms <= 600000, "diga_xgmi_set_timeout_ms: NULL communicator or %d ms outside [1, 600000]",
+                 timeout_ms);
+  c->dev.timeout_ticks = (long long)timeout_ms * XG_TICKS_PER_MS;
+  return DIGA_OK;
+}
+
+extern "C" int diga_bn_exchange_finalize(void* comm, const float* slab, int units_per_sample, int nsamples, int a_samples, int per_sample,
+                                         int C, double n_a, double n_b, const float* running_mean, const float* running_var,
+                                         const float* weight, const float* bias, float lam, float eps, float* scale, float* shift,
+                                         void* stream) {
+  XgComm* c = (XgComm*)comm;
+  DIGA_CHECK_ARG(c && c->connected, "diga_bn_exchange_finalize: communicator not connected");
+  DIGA_CHECK_ARG(slab && running_mean && running_var && weight && bias && scale && shift, "diga_bn_exchange_finalize: NULL pointer");
+  DIGA_CHECK_ARG(units_per_sample > 0 && nsamples > 0 && a_samples >= 0 && a_samples <= nsamples && n_a > 0 && n_b >= 0,
+                 "diga_bn_exchange_finalize: bad sizes units_per_sample=%d nsamples=%d a_samples=%d", units_per_sample, nsamples, a_samples);
+  DIGA_CHECK_ARG(C >= 64 && C % 64 == 0 && C / 64 <= XB_MAX_X, "diga_bn_exchange_finalize: C=%d must be a multiple of 64 up to %d", C, 64 * XB_MAX_X);
+  const int nsets = per_sample ? nsamples : 1;
+  DIGA_CHECK_ARG(nsets <= XB_MAX_SETS && nsets <= FIN_PH, "diga_bn_exchange_finalize: %d sets in flight exceed the limit %d", nsets,
+                 XB_MAX_SETS < FIN_PH ? XB_MAX_SETS : FIN_PH);
+  hipLaunchKernelGGL(bn_exchange_finalize_kernel, dim3(C / 64, nsets), dim3(64 * FIN_PH), 0, (hipStream_t)stream, c->dev, slab, units_per_sample,
+                     nsamples, a_samples, per_sample, C, n_a, n_b, running_mean, running_var, weight, bias, lam, eps, scale, shift);
+  DIGA_CHECK_LAUNCH("diga_bn_exchange_finalize");
   return DIGA_OK;
 }

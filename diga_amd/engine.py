@@ -146,7 +146,7 @@ class Engine:
     def __init__(self, weights: NetWeights, B: int, H: int, W: int, bn_lambda: float = 0.8, group=None,
                  confidence_threshold: float = 0.9, stream: bool = False, conv_tile: int = 0,
                  autotune: bool = False, fuse_conv3: bool = False, force_exchange: bool = False, fold_finalize: bool = False,
-                 fuse_apply="auto", oneshot: bool = False, fuse_finapply=False):
+                 fuse_apply="auto", oneshot=False, fuse_finapply=False, exchange_timeout_ms: int | None = None):
         """stream=False: x is ONE batch of B samples -> the reference's batch semantics (half_first DAM statistics over
         the batch, prototypes pooled over the batch).  stream=True: x holds B CONSECUTIVE batch-1 frames of a stream
         ("frames in flight"): the trunk runs once over all of them with per-sample DAM statistics (DAM carries no
@@ -203,13 +203,22 @@ class Engine:
         # the statistics / prototype exchange runs whenever there is more than one rank; force_exchange takes the same
         # code path with a single-rank group (how the RCCL calls are exercised on a one-GPU box, tests/test_gpu_dist.py)
         self.exchange = self.world > 1 or (bool(force_exchange) and group is not None)
-        # oneshot: the exchanges go through the one-launch direct-peer-write all-reduce (diga_amd/xgmi.py) instead
-        # of torch.distributed (RCCL): no host round trip per layer, capturable in a HIP graph.  Opt-in: it has been run with two
-        # ranks on one GPU only (tests/test_gpu_dist.py), never across xGMI.
+        # oneshot: the exchanges go through the one-launch direct-peer-write transport (diga_amd/xgmi.py) instead of
+        # torch.distributed (RCCL): per BN layer ONE launch (diga_bn_exchange_finalize: slab reduce + peer writes + bounded wait +
+        # rank-order sum + scale / shift), two launches for the prototype sums / counts -- no host round trip, capturable in a HIP
+        # graph.  True: required (raises when it cannot connect); "auto": used when it connects and passes its self-test on every
+        # rank, else the reason is logged and the exchanges go through torch.distributed; False: torch.distributed.
+        # Slot size in 8-BYTE elements: the fp32 prototype sums (pairs) and, for the three-launch fallback of a BN layer the fused
+        # form does not cover (more than 16 sets in flight), the fp64 group sums.
         self.oneshot = None
         if oneshot and self.exchange:
-            from .xgmi import OneShotComm
-            self.oneshot = OneShotComm(group, max_elems=max(1 << 17, B * 4 * 2048, B * 2 * weights.num_classes * (FEAT_CH + 1)))
+            from . import xgmi
+            need = max(1 << 14, (B if stream else 1) * 4 * 2048, -(-(B if stream else 1) * 2 * weights.num_classes * FEAT_CH // 2))
+            need = min(need, xgmi.MAX_ELEMS_LIMIT)       # larger tensors travel over torch.distributed (OneShotComm.supports)
+            if oneshot == "auto":
+                self.oneshot = xgmi.connect_or_none(group, need, timeout_ms=exchange_timeout_ms)
+            else:
+                self.oneshot = xgmi.OneShotComm(group, max_elems=need, timeout_ms=exchange_timeout_ms)
         # fold_finalize: where every sample is normalised with its own statistics (batch 1, or a stream's frames in flight) the
         # DAM finalize can run inside the conv launch (diga_conv_igemm_bf16_dam: the last tile of each (sample, N tile) group
         # reduces the slab) -- bit-identical scale / shift, 103 launches fewer per pass.  Measured (same-box A/B):
@@ -277,6 +286,7 @@ class Engine:
         self.hist = torch.zeros(self.C * self.C, dtype=torch.int64, device=dev)
         self.feat = None          # bf16 NHWC view of the layer4 output, set by forward_feat
         self.conv_flops = 0       # 2*MAC of the executed convs (filled by the first forward_feat)
+        self.exchange_launches = 0
         self.conv_events = None   # optional list: (name, flops, start_event, end_event) per igemm launch (bench.py)
         self.aux_events = None    # optional list: (kernel, algorithmic bytes, start_event, end_event) per HBM-bound launch (bench.py)
         self.taps = None          # optional dict: name -> (tensor, shape) of intermediate activations (tests)
@@ -291,6 +301,7 @@ class Engine:
         """Sum over ranks, in place.  RCCL ("nccl") reduces the device tensor on the stream; with the gloo backend
         (single-GPU rehearsal of the protocol in tests) the tensor takes a host round trip."""
         import torch.distributed as dist
+        self.exchange_launches += 1
         if self.oneshot is not None and self.oneshot.supports(t):
             self.oneshot.all_reduce(t)
             return
@@ -315,6 +326,11 @@ class Engine:
             return sc, sh
         if self.stream:      # B global batches in flight, one frame of each on this rank: one exchange for all of them
             _, n_a, n_b = group_plan(self.rank, self.world, 1, rows_per_sample)
+            if self.oneshot is not None and self.oneshot.supports_bn(bn.C, self.B):
+                self.exchange_launches += 1
+                self.oneshot.bn_exchange_finalize(self.slab, ups, self.B, 1 if self.rank == 0 else 0, 1, bn.C, n_a, n_b, bn.running_mean,
+                                                  bn.running_var, bn.weight, bn.bias, lam, 1e-5, sc, sh)
+                return sc, sh
             sums = self.sums[:self.B * 4 * bn.C]
             call("diga_bn_reduce_slab", _p(self.slab), ups, self.B, 1 if self.rank == 0 else 0, 1, bn.C, _p(sums), _stream())
             self._all_reduce(sums)
@@ -324,6 +340,11 @@ class Engine:
         split, n_a, n_b = self._groups(rows_per_sample)
         a_samples = split // rows_per_sample
         if self.exchange:
+            if self.oneshot is not None and self.oneshot.supports_bn(bn.C, 1):
+                self.exchange_launches += 1
+                self.oneshot.bn_exchange_finalize(self.slab, ups, self.B, a_samples, 0, bn.C, n_a, n_b, bn.running_mean, bn.running_var,
+                                                  bn.weight, bn.bias, lam, 1e-5, sc, sh)
+                return sc, sh
             sums = self.sums[:4 * bn.C]
             call("diga_bn_reduce_slab", _p(self.slab), ups, self.B, a_samples, 0, bn.C, _p(sums), _stream())
             self._all_reduce(sums)
@@ -484,6 +505,7 @@ class Engine:
         assert x.shape == (self.B, 3, self.H, self.W) and x.dtype == torch.float32 and x.is_contiguous()
         w, B = self.w, self.B
         self.conv_flops = 2 * B * self.h1 * self.w1 * 64 * 147
+        self.exchange_launches = 0     # cross-rank exchanges of this step (sharded path: 104 BN layers + 2 for the prototypes)
         bn = w.bn["bn1"]
         call("diga_stem_conv7x7s2", _p(x), _p(w.stem_w), _p(self.stem_raw), _p(self.slab), _p(bn.running_mean), B, self.H,
              self.W, _stream())
@@ -665,6 +687,18 @@ class Engine:
         call("diga_upsample_argmax_hist_frames", _p(self.probs), _p(y), int(y.dtype == torch.int64), _p(self.pred), _p(self.hist),
              _p(probs_up), self.B, self.C, self.h, self.wd, H, W, _stream())
         return self.pred
+
+    def check_exchange(self):
+        """Call at a point where the host may synchronise (never under graph capture): raises DigaError when a wait of the one-shot
+        transport has expired since the last call -- the affected statistics / prototypes were poisoned with NaN on this rank."""
+        if self.oneshot is not None:
+            self.oneshot.check()
+
+    def close(self):
+        """Unmap and free the one-shot transport's buffers (set-up memory; the exchanges themselves never allocate)."""
+        if self.oneshot is not None:
+            self.oneshot.close()
+            self.oneshot = None
 
     def reset_state(self):
         self.state_flag.zero_()

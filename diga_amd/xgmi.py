@@ -3,12 +3,19 @@
 `OneShotComm(group, max_elems)` allocates this rank's exchange buffer, shares its hipIpc handle with the ranks of `group`
 (one all_gather of 64 bytes at set-up) and maps the peers' buffers.  `all_reduce(t)` then sums a device tensor (fp64, fp32
 or int32) over the ranks in ONE kernel launch on the current stream -- deterministic (rank order), identical bits on every
-rank, no host involvement, capturable in a HIP graph.  The sharded Engine uses it for the 104 per-layer BN exchanges and
-the prototype exchange when `Engine(oneshot=True)`; torch.distributed (RCCL) stays the default transport.
+rank, no host involvement, capturable in a HIP graph; `bn_exchange_finalize(...)` is the same exchange fused into the DAM
+finalize (one launch per BN layer: slab reduce, peer writes, bounded wait, rank-order sum, scale / shift).  The sharded
+Engine uses them for the 104 per-layer BN exchanges and the prototype exchange (`Engine(oneshot=True)`;
+`connect_or_none` = "use it when it connects and passes its self-test on every rank, else say why and return None").
+
+One communicator belongs to ONE stream (two windows on two HIP streams = two communicators): its exchanges pair up across
+ranks by sequence number.  Waits are bounded (timeout_ms); a peer that does not arrive poisons the payload with NaN and
+`check()` raises -- after that the communicator is dead.
 """
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import torch
 
@@ -16,29 +23,57 @@ from . import _lib
 from ._lib import call
 
 _DT = {torch.float64: 0, torch.float32: 1, torch.int32: 2}
+MAX_ELEMS_LIMIT = 512 * 2048          # 8-byte elements per slot (csrc/xgmi.hip: XG_MAX_BLOCKS x XG_EPB)
+BN_MAX_SETS = 16                      # sets (global batches in flight) one fused BN exchange carries
+BN_MAX_C = 2048
 
 
 class OneShotComm:
-    def __init__(self, group, max_elems: int = 1 << 18):
+    def __init__(self, group, max_elems: int = 1 << 18, timeout_ms: int | None = None):
+        """max_elems: 8-BYTE elements per slot, i.e. the largest all_reduce payload in bytes / 8 (larger tensors are refused by
+        `supports` and travel over torch.distributed).  timeout_ms: bound of every wait (library default 30 s)."""
         import torch.distributed as dist
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.max_elems = int(max_elems)
+        self.max_elems = int(min(max(1, max_elems), MAX_ELEMS_LIMIT))
         _lib.load()
         self._comm = C.c_void_p()
         handle = (C.c_ubyte * 64)()
-        call("diga_xgmi_create", self.world, self.rank, self.max_elems, C.byref(self._comm), C.cast(handle, C.c_void_p))
-        mine = torch.tensor(list(handle), dtype=torch.uint8)
-        if dist.get_backend(group) == "nccl":
+        # Every rank runs the SAME collectives whatever happens locally (a rank that raised early would leave its peers inside
+        # a mismatched collective): a status byte travels with the handle, and the mapping result is agreed by a MIN all-reduce.
+        err = None
+        try:
+            call("diga_xgmi_create", self.world, self.rank, self.max_elems, C.byref(self._comm), C.cast(handle, C.c_void_p))
+            if timeout_ms is not None:
+                call("diga_xgmi_set_timeout_ms", self._comm, int(timeout_ms))
+        except _lib.DigaError as e:
+            err = e
+        on_dev = dist.get_backend(group) == "nccl"
+        mine = torch.tensor(list(handle) + [0 if err is None else 1], dtype=torch.uint8)
+        if on_dev:
             mine = mine.cuda()
         allh = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(allh, mine, group=group)
-        blob = bytes(torch.cat([h.cpu() for h in allh]).tolist())
-        self._handles = C.create_string_buffer(blob, len(blob))
-        call("diga_xgmi_connect", self._comm, C.cast(self._handles, C.c_void_p))
-        dist.barrier(group=group)          # every rank has mapped every buffer before the first exchange
+        allh = torch.stack([h.cpu() for h in allh])
+        bad = [r for r in range(self.world) if int(allh[r, 64])]
+        if not bad:
+            blob = bytes(allh[:, :64].reshape(-1).tolist())
+            self._handles = C.create_string_buffer(blob, len(blob))
+            try:
+                call("diga_xgmi_connect", self._comm, C.cast(self._handles, C.c_void_p))
+            except _lib.DigaError as e:
+                err = e
+        ok = torch.tensor([1 if (err is None and not bad) else 0], dtype=torch.int32)
+        if on_dev:
+            ok = ok.cuda()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)      # also the barrier: every rank has mapped every buffer
+        if int(ok.item()) != 1:
+            self.close()
+            raise _lib.DigaError(f"one-shot transport: set-up failed on rank {self.rank}: {err}" if err is not None else
+                                 f"one-shot transport: set-up failed on a peer (ranks {bad or 'unknown'})")
 
+    # ------------------------------------------------------------------ exchanges (enqueue only)
     def all_reduce(self, t: torch.Tensor):
         assert t.is_cuda and t.is_contiguous() and t.dtype in _DT, (t.dtype, t.device)
         call("diga_xgmi_allreduce", self._comm, C.c_void_p(t.data_ptr()), t.numel(), _DT[t.dtype],
@@ -47,11 +82,75 @@ class OneShotComm:
     def supports(self, t: torch.Tensor) -> bool:
         return t.dtype in _DT and t.numel() * t.element_size() <= self.max_elems * 8 and (t.dtype == torch.float64 or t.numel() % 2 == 0)
 
+    @staticmethod
+    def supports_bn(C_: int, nsets: int) -> bool:
+        return C_ % 64 == 0 and 64 <= C_ <= BN_MAX_C and 1 <= nsets <= BN_MAX_SETS
+
+    def bn_exchange_finalize(self, slab, ups, nsamples, a_samples, per_sample, C_, n_a, n_b, rmean, rvar, weight, bias, lam, eps, scale, shift):
+        p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+        call("diga_bn_exchange_finalize", self._comm, p(slab), ups, nsamples, a_samples, per_sample, C_, n_a, n_b, p(rmean), p(rvar),
+             p(weight), p(bias), lam, eps, p(scale), p(shift), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    # ------------------------------------------------------------------ health
     def check(self):
         """Synchronises the device; raises DigaError if a peer's contribution never arrived."""
         call("diga_xgmi_check", self._comm)
+
+    def set_timeout_ms(self, ms: int):
+        call("diga_xgmi_set_timeout_ms", self._comm, int(ms))
+
+    def self_test(self, rounds: int = 3) -> bool:
+        """A few all-reduces with known answers (fp64, fp32, int32) through the mapped buffers: True when every result is the
+        exact rank-order sum and no wait expired.  Run by every rank at set-up, before the transport is trusted with statistics."""
+        ok = True
+        n = 4 * 2048
+        base = torch.arange(1, n + 1, dtype=torch.float64, device="cuda")
+        tri = self.world * (self.world + 1) // 2
+        for r in range(rounds):
+            for dt in (torch.float64, torch.float32, torch.int32):
+                t = ((base + r) * (self.rank + 1)).to(dt)
+                self.all_reduce(t)
+                ok = ok and bool(torch.equal(t, ((base + r) * tri).to(dt)))
+        try:
+            self.check()
+        except _lib.DigaError:
+            return False
+        return ok
 
     def close(self):
         if self._comm:
             call("diga_xgmi_destroy", self._comm)
             self._comm = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 -- interpreter teardown
+            pass
+
+
+def connect_or_none(group, max_elems: int, timeout_ms: int | None = None, log=sys.stderr):
+    """The default transport decision of the sharded path: build a OneShotComm, run its self-test, and keep it only if EVERY
+    rank succeeded (one MIN all-reduce of the verdicts over `group`); otherwise log the reason once (rank 0) and return None
+    -- the caller then exchanges through torch.distributed (RCCL), launched eagerly."""
+    import torch.distributed as dist
+    comm, why = None, ""
+    try:
+        comm = OneShotComm(group, max_elems=max_elems, timeout_ms=5000)
+        if not comm.self_test():
+            why = "self-test failed (wrong sum or expired wait)"
+    except Exception as e:          # noqa: BLE001 -- hipIpc refusals surface as DigaError, rendezvous trouble as RuntimeError
+        why = f"{type(e).__name__}: {e}"
+    verdict = torch.tensor([0 if why else 1], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        verdict = verdict.cuda()
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+    if int(verdict.item()) == 1:
+        comm.set_timeout_ms(timeout_ms if timeout_ms is not None else 30000)
+        return comm
+    if dist.get_rank(group) == 0 or why:
+        print(f"[diga_amd] one-shot peer-write transport unavailable on rank {dist.get_rank(group)}: {why or 'a peer failed'}; "
+              "falling back to torch.distributed all-reduces, launched eagerly", file=log, flush=True)
+    if comm is not None:
+        comm.close()
+    return None

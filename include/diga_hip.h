@@ -12,7 +12,8 @@
  * Conventions (all entry points):
  *   - every pointer is a DEVICE pointer on the current HIP device unless its name ends in _host;
  *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it;
- *   - no entry point allocates, frees or synchronises (safe under stream capture);
+ *   - no entry point allocates, frees or synchronises (safe under stream capture) -- except the SET-UP calls of the one-shot
+ *     exchange (diga_xgmi_create / _connect / _destroy allocate and map its buffer) and diga_xgmi_check (synchronises);
  *   - return value: 0 on success, negative DIGA_E* on error (never throws);
  *     diga_last_error_string() describes the last error of the calling thread;
  *   - activations are NHWC ("pixels x channels") bf16 (raw uint16_t bit patterns), statistics,
@@ -346,7 +347,16 @@ int diga_upsample_argmax_hist_frames(const float* probs, const void* target, int
  *   diga_xgmi_destroy
  * diga_xgmi_allreduce: in-place sum over ranks of `count` values at `data` (device, 8-byte aligned); dtype 0 = fp64,
  *   1 = fp32, 2 = int32 (4-byte types: count even); count*size <= max_elems*8.  Every rank must issue the same sequence of
- *   calls (same counts).  diga_xgmi_check (synchronises the device) reports a peer that never arrived.
+ *   calls (same counts) on ONE stream per communicator (two streams = two communicators).
+ * Waits are bounded by wall-clock time (default 30 s, diga_xgmi_set_timeout_ms): when a peer has not arrived by then the launch
+ *   ends, POISONS its payload (NaN for fp64 / fp32, INT32_MIN for int32, NaN scale / shift) and raises a sticky error word;
+ *   diga_xgmi_check (synchronises the device) turns that word into DIGA_ELAUNCH.  A communicator that has failed is dead.
+ * diga_bn_exchange_finalize: the exchange FUSED into the DAM finalize -- one launch per BN layer instead of
+ *   diga_bn_reduce_slab + diga_xgmi_allreduce + diga_bn_finalize_sums (same arguments as the first and the last; same fixed
+ *   summation orders, so scale / shift are bit-identical to the three-launch form): every (64-channel block, set) block reduces
+ *   its part of the local slab and writes its fp64 group sums into every rank's buffer; the last block of a channel block
+ *   raises the flag, waits for the peers, sums in rank order and writes scale / shift [nsets][C] (ttda:313-343 on the GLOBAL
+ *   batch).  Limits: C % 64 == 0, C <= 2048, at most 16 sets (per_sample: nsamples <= 16).
  * ------------------------------------------------------------------------------------------ */
 int64_t diga_xgmi_buffer_bytes(int world, int64_t max_elems);
 int diga_xgmi_create(int world, int rank, int64_t max_elems, void** comm_out, void* ipc_handle_out64);
@@ -354,6 +364,11 @@ int diga_xgmi_connect(void* comm, const void* handles_world_x64);
 int diga_xgmi_destroy(void* comm);
 int diga_xgmi_allreduce(void* comm, void* data, int64_t count, int dtype, void* stream);
 int diga_xgmi_check(void* comm);
+int diga_xgmi_set_timeout_ms(void* comm, int timeout_ms);
+int diga_bn_exchange_finalize(void* comm, const float* slab, int units_per_sample, int nsamples, int a_samples,
+                              int per_sample, int C, double n_a, double n_b, const float* running_mean,
+                              const float* running_var, const float* weight, const float* bias, float lam, float eps,
+                              float* scale, float* shift, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Input pipeline: the arithmetic the reference's datasets apply to a decoded frame.

@@ -407,6 +407,72 @@ def gen_net_long(m):
     np.savez_compressed(os.path.join(GOLD, "net_long.npz"), **out)
 
 
+def gen_net_hires(m):
+    """BASELINE configs[3]'s resolution: 2048x1024 frames, B = 1, two frames (seed branch + EMA branch) -> the 129x257 feature
+    grid of adaptseg.py:177-188.  logits / probs sub-sampled, integer decisions and their flip margins in full (B = 4 at this
+    size needs > 40 GB of cal_pred_of_proto temporaries, SURVEY 8c: the batch rule itself is pinned at small sizes)."""
+    out = {}
+    frames = [synth.synth_frame(t, 1, 1024, 2048) for t in range(2)]
+    res, metric = run_sequence(m, frames)
+    for t, r in enumerate(res):
+        out[f"hr_{t}_x_sha"] = np.array(sha(frames[t][0]))
+        out[f"hr_{t}_y_sha"] = np.array(sha(frames[t][1]))
+        out[f"hr_{t}_feat_sub"] = np_(r["feat"][:, ::32, ::4, ::4])
+        out[f"hr_{t}_feat_mean_ch"] = np_(r["feat"].mean([0, 2, 3]))
+        out[f"hr_{t}_logits_sub"] = np_(r["logits"][:, :, ::2, ::2])
+        out[f"hr_{t}_probs_sub"] = np_(r["probs"][:, :, ::2, ::2])
+        for k in ("run", "rflag", "hist"):
+            out[f"hr_{t}_{k}"] = np_(r[k])
+        out[f"hr_{t}_pseudo"] = np_(r["pseudo"]).astype(np.uint8)
+        out[f"hr_{t}_pred"] = np_(r["pred"]).astype(np.uint8)
+        out[f"hr_{t}_pl_pmax"] = np_(r["pl_pmax"])
+        out[f"hr_{t}_pl_gap_bucket"] = gap_bucket(r["pl_gap"])
+        out[f"hr_{t}_pred_gap_bucket"] = gap_bucket(r["pred_gap"])
+        out[f"hr_{t}_lowmass"] = np.packbits(np_(r["lowmass"]))
+        out[f"hr_{t}_pred_nan"] = np.packbits(np_(r["pred_nan"]))
+        print("hires frame", t, float(metric.compute()), flush=True)
+    out["hr_shape"] = np.array([1, 1024, 2048])
+    out["hr_miou"] = np.array([float(metric.compute()), float(metric.compute_iou("16")), float(metric.compute_iou("13"))])
+    np.savez_compressed(os.path.join(GOLD, "net_hires.npz"), **out)
+
+
+EVAL_FRAMES = 500
+EVAL_EVERY = 50
+
+
+def gen_net_eval500(m):
+    """One evaluation-length batch-1 stream: 500 frames of 1024x512 (GTA5 -> Cityscapes val has 500 images, README.md:241-243;
+    frame t = synth_frame(t): the first 30 frames are net_stream.npz's), fresh prototypes, forward_and_adapt + Upsample +
+    SegmentationMetric (ttda:1605-1660).  Stored: the cumulative confusion matrix, mIoU-19/16/13, the running prototypes' norms and
+    flags every 50 frames, and the final prototypes."""
+    out = {}
+    if hasattr(m, "classifier_running_proto"):
+        del m.classifier_running_proto
+    metric = T.SegmentationMetric(num_classes=19, ignore_index=255)
+    nan_px = 0
+    for t in range(EVAL_FRAMES):
+        x, y = synth.synth_frame(t, 1, 512, 1024)
+        x, y = torch.from_numpy(x), torch.from_numpy(y)
+        with torch.no_grad():
+            probs, _ = m.forward_and_adapt((x, y))
+            up = torch.nn.Upsample(size=y.shape[-2:], mode="bilinear")(probs)
+            metric.update(up, y)
+        nan_px += int(torch.isnan(probs).any(1).sum())
+        if (t + 1) % EVAL_EVERY == 0:
+            out[f"ev_{t + 1}_hist"] = np_(metric.hist).astype(np.int64)
+            out[f"ev_{t + 1}_miou"] = np.array([float(metric.compute()), float(metric.compute_iou("16")), float(metric.compute_iou("13"))])
+            out[f"ev_{t + 1}_run_norm"] = np_(m.classifier_running_proto.norm(dim=1))
+            out[f"ev_{t + 1}_rflag"] = np_(m.classifier_running_proto_exists_flag)
+            out[f"ev_{t + 1}_nan_pixels"] = np.int64(nan_px)
+            print("eval stream frame", t + 1, out[f"ev_{t + 1}_miou"], flush=True)
+            np.savez_compressed(os.path.join(GOLD, "net_eval500.partial.npz"), **out)
+    out["ev_run_final"] = np_(m.classifier_running_proto)
+    out["ev_frames"] = np.int64(EVAL_FRAMES)
+    out["ev_every"] = np.int64(EVAL_EVERY)
+    np.savez_compressed(os.path.join(GOLD, "net_eval500.npz"), **out)
+    os.remove(os.path.join(GOLD, "net_eval500.partial.npz"))
+
+
 def gen_net_b8(m):
     """BASELINE configs[2]'s batch: ONE batch of 8 frames (half_first = sample 0 vs samples 1..7, ttda:313-320), the
     reference run with batch_size 8.  b8s: 65x129 inputs, 3 frames (everything stored); b8f: 1024x512, 2 frames (seed +
@@ -543,7 +609,7 @@ def gen_fn_input():
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
     which = sys.argv[1:] or ["bn", "sam", "tail", "small", "full", "multires", "stream", "loader", "input"]
-    m = make_diga() if set(which) & {"sam", "tail", "small", "full", "multires", "stream", "streams_ms", "long", "b8"} else None
+    m = make_diga() if set(which) & {"sam", "tail", "small", "full", "multires", "stream", "streams_ms", "long", "b8", "hires", "eval500"} else None
     if "bn" in which:
         gen_fn_bn()
     if "sam" in which:
@@ -564,6 +630,10 @@ if __name__ == "__main__":
         gen_net_streams_ms(m)
     if "long" in which:
         gen_net_long(m)
+    if "hires" in which:
+        gen_net_hires(m)
+    if "eval500" in which:
+        gen_net_eval500(m)
     if "loader" in which:
         gen_loader()
     if "input" in which:

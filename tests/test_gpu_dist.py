@@ -18,7 +18,8 @@ def _worker(rank, world, port, q, k):
     os.makedirs("gpurun_out", exist_ok=True)
     log = open(f"gpurun_out/dist_rank{rank}.log", "w")
     try:
-        (_worker_oneshot if k == 100 else _worker_b8 if k == 8 else _worker_windows if k < 0 else _worker_stream if k > 1 else _worker_body)(rank, world, port, q, log, k)
+        (_worker_oneshot if k == 100 else _worker_oneshot_stream if k == 101 else _worker_late_peer if k == 102 else
+         _worker_missing_peer if k == 103 else _worker_b8 if k == 8 else _worker_windows if k < 0 else _worker_stream if k > 1 else _worker_body)(rank, world, port, q, log, k)
     except Exception:
         traceback.print_exc(file=log)
         log.flush()
@@ -140,6 +141,117 @@ def _worker_oneshot(rank, world, port, q, log, k):
     print("graph replay", "identical" if graph_ok else "DIFFERENT", file=log, flush=True)
     dist.barrier()
     q.put((rank, dict(ok=ok and graph_ok, frames=out)))
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+def _worker_oneshot_stream(rank, world, port, q, log, k):
+    """3 global batches in flight through the FUSED exchange (diga_bn_exchange_finalize, per_sample sets), then the same window
+    of 15 batches in flight at the bench's default size class (constructs the B = 15 communicator: ADVICE r2)."""
+    import torch.distributed as dist
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
+    K = 3
+    eng = Engine(w, K, H, W, group=dist.group.WORLD, stream=True, oneshot=True)
+    xy = [synth.synth_frame(t, world, H, W) for t in range(K)]
+    x = torch.from_numpy(np.concatenate([a[rank:rank + 1] for a, _ in xy])).cuda()
+    y = torch.from_numpy(np.concatenate([b[rank:rank + 1] for _, b in xy])).cuda()
+    probs = eng.forward_and_adapt(x, y, CFG)
+    torch.cuda.synchronize()
+    eng.check_exchange()
+    launches = eng.exchange_launches
+    print("window done,", launches, "exchange launches", file=log, flush=True)
+    out = dict(probs=probs.cpu().numpy(), logits=eng.logits.cpu().numpy(), run=eng.run_proto.cpu().numpy(), rflag=eng.run_flag.cpu().numpy(),
+               launches=launches)
+    eng.close()
+    # 15 batches in flight: the prototype sums (15 x 2 x 19 x 2048 fp32) must fit the communicator the engine sizes for itself
+    big = Engine(w, 15, H, W, group=dist.group.WORLD, stream=True, oneshot=True)
+    xb = torch.from_numpy(np.concatenate([synth.synth_frame(t, world, H, W)[0][rank:rank + 1] for t in range(15)])).cuda()
+    yb = torch.from_numpy(np.concatenate([synth.synth_frame(t, world, H, W)[1][rank:rank + 1] for t in range(15)])).cuda()
+    big.forward_and_adapt(xb, yb, CFG)
+    torch.cuda.synchronize()
+    big.check_exchange()
+    out["big_ok"] = bool(big.oneshot.supports(big.pool_sums) and big.exchange_launches == 106 and torch.isfinite(big.scale).all())
+    out["big_logits3"] = big.logits[:3].cpu().numpy()
+    big.close()
+    dist.barrier()
+    q.put((rank, out))
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+def _worker_late_peer(rank, world, port, q, log, k):
+    """A peer that arrives 2 s late is waited for (the wait is bounded by wall-clock time, 10 s here), not an error."""
+    import time
+
+    import torch.distributed as dist
+    from diga_amd.xgmi import OneShotComm
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    comm = OneShotComm(dist.group.WORLD, max_elems=1 << 14, timeout_ms=10000)
+    t = torch.full((4096,), float(rank + 1), dtype=torch.float64, device="cuda")
+    if rank == 1:
+        time.sleep(2.0)
+    t0 = time.perf_counter()
+    comm.all_reduce(t)
+    torch.cuda.synchronize()
+    waited = time.perf_counter() - t0
+    comm.check()
+    ok = bool((t == 3.0).all())
+    print("late peer: waited", round(waited, 2), "s, sum", "ok" if ok else "WRONG", file=log, flush=True)
+    dist.barrier()
+    comm.close()
+    q.put((rank, dict(ok=ok, waited=waited)))
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+def _worker_missing_peer(rank, world, port, q, log, k):
+    """A peer that never arrives: the launch ends after the time-out, the payload is poisoned (NaN / INT32_MIN / NaN scale and
+    shift) and check() raises -- no hang, no plausible-looking un-reduced numbers."""
+    import time
+
+    import torch.distributed as dist
+    from diga_amd._lib import DigaError
+    from diga_amd.xgmi import OneShotComm
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    comm = OneShotComm(dist.group.WORLD, max_elems=1 << 14, timeout_ms=1000)
+    res = dict(ok=True)
+    if rank == 0:
+        f64 = torch.ones(5000, dtype=torch.float64, device="cuda")
+        f32 = torch.ones(64, dtype=torch.float32, device="cuda")
+        i32 = torch.ones(38, dtype=torch.int32, device="cuda")
+        t0 = time.perf_counter()
+        comm.all_reduce(f64)
+        comm.all_reduce(f32)
+        comm.all_reduce(i32)
+        Cc, ups = 128, 5
+        slab = torch.randn(ups * 2 * Cc, device="cuda")
+        one = torch.ones(Cc, device="cuda")
+        sc, sh = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+        comm.bn_exchange_finalize(slab, ups, 1, 1, 0, Cc, 160.0, 160.0, one, one, one, one, 0.8, 1e-5, sc, sh)
+        torch.cuda.synchronize()
+        took = time.perf_counter() - t0
+        raised = False
+        try:
+            comm.check()
+        except DigaError:
+            raised = True
+        res = dict(ok=bool(torch.isnan(f64).all() and torch.isnan(f32).all() and (i32 == -2 ** 31).all() and torch.isnan(sc).all()
+                           and torch.isnan(sh).all() and raised and 3.5 < took < 20), took=took, raised=raised)
+        print("missing peer:", res, file=log, flush=True)
+    dist.barrier()          # rank 1 only ever comes here
+    q.put((rank, res))
     try:
         dist.destroy_process_group()
     except Exception:
@@ -339,6 +451,62 @@ def test_two_ranks_oneshot_allreduce_and_engine():
             assert np.nanmax(np.abs(got["probs"][0] - probs.cpu().numpy()[r])) < 1e-4
             assert np.array_equal(got["rflag"], eng.run_flag.cpu().numpy())
         assert np.array_equal(res[0]["frames"][t]["run"], res[1]["frames"][t]["run"])
+
+
+def test_two_ranks_fused_exchange_stream_of_global_batches():
+    """SURVEY 8 f2 as specified: the exchange fused into the finalize, one launch per BN layer for all batches in flight
+    (104 + 2 exchange launches per step).  3 global batches of 2 in flight on 2 ranks == the single-process batch-2 engine run
+    batch after batch: logits bit-identical, SAM state up to fp32 rounding; and the 15-in-flight communicator constructs."""
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    K = 3
+    res = _run_ranks(101)
+    assert res[0]["launches"] == 106 and res[1]["launches"] == 106
+    assert res[0]["big_ok"] and res[1]["big_ok"]
+    w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
+    eng = Engine(w, 2, H, W)
+    for t in range(K):
+        x, y = synth.synth_frame(t, 2, H, W)
+        probs = eng.forward_and_adapt(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), CFG)
+        torch.cuda.synchronize()
+        for r in range(2):
+            assert np.array_equal(res[r]["logits"][t], eng.logits.cpu().numpy()[r]), (t, r)
+            assert np.array_equal(res[r]["big_logits3"][t], eng.logits.cpu().numpy()[r]), (t, r)
+            a, b = res[r]["probs"][t], probs.cpu().numpy()[r]
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.nanmax(np.abs(a - b)) < 1e-4, (t, r)
+    ref_run = eng.run_proto.cpu().numpy()
+    assert np.array_equal(res[0]["run"], res[1]["run"]) and np.array_equal(res[0]["rflag"], eng.run_flag.cpu().numpy())
+    assert np.abs(res[0]["run"] - ref_run).max() <= 1e-5 * np.abs(ref_run).max()
+
+
+def test_oneshot_waits_for_a_late_peer():
+    res = _run_ranks(102)
+    assert res[0]["ok"] and res[1]["ok"]
+    assert res[0]["waited"] > 1.5, res[0]          # rank 0 really sat in the bounded wait
+
+
+def test_oneshot_missing_peer_poisons_and_raises():
+    res = _run_ranks(103)
+    assert res[0]["ok"], res[0]
+
+
+def test_bench_spawns_its_own_ranks_and_replays_a_graph():
+    """`python bench.py --gpus 2` with no launcher: two fresh rank processes (sharing this box's GPU: a rehearsal), the one-shot
+    transport connects, the sharded step is a HIP-graph replay with 104 + 2 exchange launches per window."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--height", "65",
+                        "--width", "129", "--frames-in-flight", "3", "--windows", "2", "--no-autotune"], env=env, capture_output=True,
+                       timeout=300, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["launch"] == "hipGraph replay", line["config"]
+    assert line["config"]["exchange_launches_per_step"] == 2 * 106, line["config"]
+    assert "one-shot" in line["config"]["exchange_transport"] and "rehearsal" in line
+    assert line["value"] > 0
 
 
 def _rccl_worker(port, q):
