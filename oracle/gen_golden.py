@@ -449,8 +449,17 @@ def gen_net_eval500(m):
     if hasattr(m, "classifier_running_proto"):
         del m.classifier_running_proto
     metric = T.SegmentationMetric(num_classes=19, ignore_index=255)
-    nan_px = 0
-    for t in range(EVAL_FRAMES):
+    nan_px, t_start = 0, 0
+    ckpt = os.environ.get("GOLDEN_EVAL_CKPT", "/tmp/gold/eval500_state.npz")     # resumable: an hour of CPU
+    if os.path.exists(ckpt):
+        with np.load(ckpt, allow_pickle=False) as z:
+            out = {k: z[k] for k in z.files if k.startswith("ev_")}
+            t_start, nan_px = int(z["t_next"]), int(z["nan_px"])
+            metric.hist.copy_(torch.from_numpy(z["hist"]))
+            m.classifier_running_proto = torch.from_numpy(z["run"]).clone()
+            m.classifier_running_proto_exists_flag = torch.from_numpy(z["rflag"]).clone()
+        print("resuming the eval stream at frame", t_start, flush=True)
+    for t in range(t_start, EVAL_FRAMES):
         x, y = synth.synth_frame(t, 1, 512, 1024)
         x, y = torch.from_numpy(x), torch.from_numpy(y)
         with torch.no_grad():
@@ -465,12 +474,15 @@ def gen_net_eval500(m):
             out[f"ev_{t + 1}_rflag"] = np_(m.classifier_running_proto_exists_flag)
             out[f"ev_{t + 1}_nan_pixels"] = np.int64(nan_px)
             print("eval stream frame", t + 1, out[f"ev_{t + 1}_miou"], flush=True)
-            np.savez_compressed(os.path.join(GOLD, "net_eval500.partial.npz"), **out)
+        if (t + 1) % 10 == 0:
+            os.makedirs(os.path.dirname(ckpt), exist_ok=True)
+            np.savez(ckpt + ".tmp.npz", t_next=np.int64(t + 1), nan_px=np.int64(nan_px), hist=np_(metric.hist),
+                     run=np_(m.classifier_running_proto), rflag=np_(m.classifier_running_proto_exists_flag), **out)
+            os.replace(ckpt + ".tmp.npz", ckpt)
     out["ev_run_final"] = np_(m.classifier_running_proto)
     out["ev_frames"] = np.int64(EVAL_FRAMES)
     out["ev_every"] = np.int64(EVAL_EVERY)
     np.savez_compressed(os.path.join(GOLD, "net_eval500.npz"), **out)
-    os.remove(os.path.join(GOLD, "net_eval500.partial.npz"))
 
 
 def gen_net_b8(m):
