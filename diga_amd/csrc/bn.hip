@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * FIN_PH) void bn_finalize_apply_kernel(
   double s[4];
   slab_group_sums(slab, a0, a1, b1, C, c, c < C, red, s);
   if (ph == 0 && c < C) {
-    dam_affine_from_sums(s, c, n_a, n_b, rmean, rvar, weight, bias, lam, eps, lsc - cbase, lsh - cbase);
+    dam_affine_from_sums(s, c, n_a, n_b, rmean, rvar, weight, bias, lam, eps, lsc, lsh, lane);
     if (blockIdx.y == 0) {
       scale[c] = lsc[lane];
       shift[c] = lsh[lane];

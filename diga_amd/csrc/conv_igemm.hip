@@ -736,7 +736,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
 #endif
   if constexpr (STATS) {
     if (p.fin_ticket) {
-      // ---- fused DAM finalize.  The XCDs' L2s are not coherent with each other inside a launch: this block's slab values went
+      // ---- fused DAM finalize.  gfx942 / gfx950 SPECIFIC memory ordering (this library is built for gfx950 only): the hand-off
+      // below is not the HIP memory model's release / acquire pair -- a release fence writes the whole L2 back and an acquire
+      // invalidates it, see the measurement below -- it relies on (a) agent-scope atomic stores being write-through to memory
+      // on these parts, (b) s_waitcnt vmcnt(0) returning only once those stores are performed at the memory side, (c) agent-scope
+      // atomic loads bypassing the reader's L2.  The XCDs' L2s are not coherent with each other inside a launch: this block's slab values went
       // out as agent-scope write-through stores, it takes a ticket for its (sample, N tile) group, and the block that draws the
       // last ticket reduces the group with agent-scope (L2-bypassing) loads: the arithmetic and the summation order are those
       // of bn_finalize_kernel (dam_affine.h), so scale / shift are bit-identical to the two-launch form.

@@ -51,7 +51,9 @@ __device__ __forceinline__ void slab_group_sums(const float* __restrict__ slab, 
 __device__ __forceinline__ void dam_affine_from_sums(const double* s, int c, double n_a, double n_b, const float* __restrict__ rmean,
                                                      const float* __restrict__ rvar, const float* __restrict__ weight,
                                                      const float* __restrict__ bias, float lam, float eps,
-                                                     float* __restrict__ scale, float* __restrict__ shift) {
+                                                     float* __restrict__ scale, float* __restrict__ shift, int out_index = -1) {
+  // out_index >= 0: the affine goes to scale / shift [out_index] instead of [c] (a block-local array)
+  const int oc = out_index >= 0 ? out_index : c;
   const double K = (double)rmean[c];
   const double ma = s[0] / n_a;
   float mean_cur = (float)(K + ma);
@@ -67,6 +69,6 @@ __device__ __forceinline__ void dam_affine_from_sums(const double* s, int c, dou
   const float mean = lam * rmean[c] + oml * mean_cur;
   const float var = lam * rvar[c] + oml * var_cur;
   const float sc = weight[c] / sqrtf(var + eps);
-  scale[c] = sc;
-  shift[c] = bias[c] - mean * sc;
+  scale[oc] = sc;
+  shift[oc] = bias[c] - mean * sc;
 }

@@ -387,7 +387,8 @@ class DIGA(_ModuleBase):
         if precision not in ("bf16", "fp32x2", "fp32x3"):
             raise ValueError(f"precision {precision!r}: expected 'bf16', 'fp32x2' or 'fp32x3'")
         if _pl is not None:
-            self.save_hyperparameters(logger=False)           # ttda:1569: hparams.net / dataset_info / cfg as the reference keeps them
+            # ttda:1569: hparams.net / dataset_info / cfg as the reference keeps them (the build's own arguments stay out of it)
+            self.save_hyperparameters(logger=False, ignore=["process_group", "precision"])
             for k in ("dataset_info", "cfg"):                 # item AND attribute access on both (ttda:1573 vs ttda:1640)
                 self.hparams[k] = _attr(self.hparams[k])
         else:
@@ -399,6 +400,7 @@ class DIGA(_ModuleBase):
                                        for _ in self.hparams.dataset_info["test_list"]])
         self.test_step_global = 0
         self.logged = {}
+        self._epoch_result = None      # set by the first epoch-end hook of an epoch, cleared by the next test step
         self._replace_bn()
         self._configure_bn_running_stats()
         Cn = self.hparams.dataset_info["num_classes"]
@@ -439,16 +441,26 @@ class DIGA(_ModuleBase):
             return
         super().__delattr__(name)
 
+    def _in_trainer(self) -> bool:
+        """Attached to a Lightning Trainer?  The private attribute is `_trainer` in Lightning 1.6+ / 2.x (the public `trainer`
+        property RAISES when detached in 2.x) and the plain attribute `trainer` before that."""
+        if _pl is None:
+            return False
+        d = self.__dict__
+        return d.get("_trainer") is not None or d.get("trainer") is not None
+
     def log(self, name, value, **kw):
         self.logged[name] = float(value) if torch.is_tensor(value) and value.numel() == 1 else value
-        if _pl is not None and getattr(self, "_trainer", None) is not None:      # inside trainer.test: Lightning's own logging too
+        if self._in_trainer():         # inside trainer.test: Lightning's own logging too
             super().log(name, value, **kw)
 
     def on_test_start(self):
         pass
 
     def on_test_epoch_end(self):
-        """Lightning >= 2.0 spelling of the epoch-end hook (test_epoch_end(outputs) is the 1.x one the reference uses, ttda:1647)."""
+        """Lightning >= 2.0 spelling of the epoch-end hook (test_epoch_end(outputs) is the 1.x one the reference uses, ttda:1647).
+        Lightning 1.x fires BOTH hooks: whichever comes second in an epoch returns the first one's result and logs nothing (the
+        metrics have been reset by then; computing them again would overwrite the logged mIoU with NaN)."""
         return self.test_epoch_end(None)
 
     # ---- reference API
@@ -486,6 +498,7 @@ class DIGA(_ModuleBase):
             loss, preds, targets, info = self.step(batch)
             self.test_acc[dataloader_idx].add_counts(info["hist"])
             acc = self.test_acc[dataloader_idx].compute()
+        self._epoch_result = None
         self.log("test/loss", loss)
         self.log("test/acc", acc)
         self.test_step_global += 1
@@ -507,6 +520,7 @@ class DIGA(_ModuleBase):
         eng.hist.zero_()
         eng.tail(y)
         self.test_acc[dataloader_idx].add_counts(eng.hist.reshape(eng.C, eng.C))
+        self._epoch_result = None
         self.log("test/loss", torch.tensor(0.0))
         self.log("test/acc", self.test_acc[dataloader_idx].compute())
         self.test_step_global += len(batches)
@@ -529,6 +543,8 @@ class DIGA(_ModuleBase):
         return (probs.cpu() if to_cpu else probs), {}
 
     def test_epoch_end(self, outputs: List[Any] = None):
+        if self._epoch_result is not None:          # the other spelling of the hook has already closed this epoch
+            return self._epoch_result
         accs = [m.compute() for m in self.test_acc]
         self.log("test/acc/mean", sum(accs) / len(accs))
         res = {}
@@ -540,6 +556,7 @@ class DIGA(_ModuleBase):
             self.log(f"test/acc/dataloaderr13_idx_{i}", res[i]["miou13"])
         for m in self.test_acc:
             m.reset()
+        self._epoch_result = res
         return res
 
     # ---- SAM helpers with the reference's signatures, each one a kernel call (NCHW fp32 tensors in/out).

@@ -179,18 +179,36 @@ def test_diga_is_a_lightning_module_when_lightning_is_importable():
     import subprocess
     import sys
     code = """
-import functools, sys
+import functools, sys, math
+import torch
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import ref_stubs; ref_stubs.install()
 import pytorch_lightning as pl
+pl_logged = []
+pl.LightningModule.log = lambda self, name, value, **kw: pl_logged.append(name)      # what Lightning's own log() would receive
 from diga_amd import ttda_module as T
 assert issubclass(T.DIGA, pl.LightningModule)
 m = T.DIGA(net=functools.partial(T.DeepLabv2AdaptSeg, multi_level=True, restore_from=None),
            dataset_info=dict(num_classes=19, image_size=(321, 321), test_list=[0], class_names=[str(i) for i in range(19)]),
            cfg=dict(bn_lambda=0.8, proto_lambda=0.8, fusion_lambda=0.8, confidence_threshold=0.9, proto_rho=0.1))
 assert m.hparams.dataset_info["num_classes"] == 19 and m.hparams.dataset_info.class_names[3] == "3" and m.hparams.cfg.bn_lambda == 0.8
-assert "net" in m.hparams and callable(m.on_test_epoch_end) and callable(m.test_epoch_end) and callable(m.on_test_start)
-m.log("test/acc", 1.5); assert m.logged["test/acc"] == 1.5
+assert m.hparams["cfg"]["proto_rho"] == 0.1 and m.hparams.cfg["proto_rho"] == 0.1              # item AND attribute access (ttda:1573 / 1640)
+assert "net" in m.hparams and "process_group" not in m.hparams and "precision" not in m.hparams
+assert callable(m.on_test_epoch_end) and callable(m.test_epoch_end) and callable(m.on_test_start)
+# log(): outside a trainer only the module's own record; inside one Lightning's log() is called too
+m.log("test/acc", 1.5); assert m.logged["test/acc"] == 1.5 and pl_logged == []
+m._trainer = object()
+m.log("test/acc", 2.5); assert m.logged["test/acc"] == 2.5 and pl_logged == ["test/acc"]
+# both epoch-end hook spellings in one epoch (Lightning 1.x fires both): the second returns the first one's result and
+# must not overwrite the logged mIoU with the NaN of the already-reset metric
+h = torch.zeros(19, 19); h[0, 0] = 5; h[1, 1] = 3; h[0, 1] = 1
+m.test_acc[0].add_counts(h)
+r1 = m.on_test_epoch_end()
+first = m.logged["test/acc/dataloaderr_idx_0"]
+n_logged = len(pl_logged)
+r2 = m.test_epoch_end([])
+assert r2 is r1 and m.logged["test/acc/dataloaderr_idx_0"] == first and not math.isnan(first) and len(pl_logged) == n_logged
+assert abs(first - 100 * (5 / 6 + 3 / 4) / 2) < 1e-4, first
 print("LIGHTNING_OK")
 """ % (ROOT, os.path.join(ROOT, "oracle"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
