@@ -117,6 +117,58 @@ def cpu_baseline(nframes_timed=10, H=512, W=1024):
                        f"confusion matrix), torch {torch.__version__} CPU")
 
 
+def exact_mode(dev, precision, fif, steps, H=512, W=1024):
+    """Throughput of the fp32-exact verification mode (diga_amd/verify.py: the SAME MFMA kernels with 2 / 3 bf16 operand planes,
+    fp32 activations and statistics) -- the only configuration that meets the north star's numeric bar END TO END (the reference
+    is fp32 end to end, ttda:1634-1645) -- on the same stream, `fif` frames in flight per step, HIP-graph replay; and its logit
+    error against the reference's own logits for the first frames of the stream (tests/golden/net_stream.npz)."""
+    from diga_amd import synth
+    from diga_amd.verify import ExactEngine, ExactWeights
+    nplanes = {"fp32x2": 2, "fp32x3": 3}[precision]
+    w = ExactWeights(synth.synth_params(0), dev, nplanes=nplanes)
+    eng = ExactEngine(w, fif, H, W, bn_lambda=CFG["bn_lambda"], stream=fif > 1)
+    wins = []
+    for i in range(2):
+        xy = [synth.synth_frame(i * fif + k, 1, H, W) for k in range(fif)]
+        wins.append((torch.from_numpy(np.concatenate([a for a, _ in xy])).to(dev), torch.from_numpy(np.concatenate([b for _, b in xy])).to(dev)))
+    # parity first (fresh prototypes, frames 0 .. fif-1 of the seed-0 stream): logits against the reference's
+    err = None
+    gpath = os.path.join(ROOT, "tests", "golden", "net_stream.npz")
+    eng.forward_and_adapt(*wins[0], CFG)
+    eng.tail(wins[0][1])
+    torch.cuda.synchronize()
+    if os.path.exists(gpath):
+        with np.load(gpath, allow_pickle=False) as z:
+            got = eng.logits[:, :, ::4, ::4].cpu().numpy()
+            errs = []
+            for t in range(min(fif, int(z["st_frames"]))):
+                ref = z[f"st_{t}_logits_sub"][0]
+                errs.append(float(np.abs(got[t] - ref).max() / (ref.max() - ref.min())))
+            err = max(errs)
+    eng.forward_and_adapt(*wins[1], CFG)
+    eng.tail(wins[1][1])
+    torch.cuda.synchronize()
+    graphs = []
+    for x, y in wins:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            eng.forward_and_adapt(x, y, CFG)
+            eng.tail(y)
+        graphs.append(g)
+    graphs[0].replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        graphs[i % 2].replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"precision": precision, "operand_planes": nplanes, "mfma_terms_per_product": 3 if nplanes == 2 else 6,
+            "value": round(fif * steps / dt, 2), "unit": "frames/s", "frames_per_step": fif, "steps": steps,
+            "ms_per_step": round(dt / steps * 1e3, 3), "launch": "hipGraph replay",
+            "logit_err_of_range_vs_reference": None if err is None else float(f"{err:.3g}"),
+            "logit_err_source": "max |logits - reference| / range over the first frames of the seed-0 stream (tests/golden/net_stream.npz, 4x4 sub-sampled)"}
+
+
 def miou_vs_reference(weights, dev, fif, nwin, autotune, seed=0):
     """The "mIoU delta vs ref" half of BASELINE.json's metric: the first frames of a synthetic batch-1 stream through the
     SAME configuration the throughput is measured in (nwin windows of fif frames in flight), fresh prototypes, against the
@@ -331,6 +383,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="skip the library-GEMM / device-copy peak check")
     ap.add_argument("--no-latency-mode", action="store_true", help="skip the extra one-frame-per-step measurement")
+    ap.add_argument("--no-exact-mode", action="store_true", help="skip the throughput / logit-error leg of the fp32-exact verification mode")
     ap.add_argument("--no-miou", action="store_true", help="skip the mIoU-vs-reference leg (8 frames through the measured configuration)")
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="N=1 only: run the N>1 code path (eager launches, one window, per-layer reduce_slab + RCCL all-reduce + "
@@ -378,7 +431,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29700 + os.getpid() % 200}", rank=0, world_size=1, device_id=dev)
         group = dist.group.WORLD
-        args.no_miou, args.no_latency_mode = True, True
+        args.no_miou, args.no_latency_mode, args.no_exact_mode = True, True, True
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from diga_amd import synth
@@ -492,6 +545,14 @@ def main():
                 "bn_apply": {"achieved_gbs": round(sum(b for b, _ in ap) / (sum(t for _, t in ap) * 1e-3) / 1e9, 1), "launches": len(ap),
                              "kernel_ms": round(sum(t for _, t in ap), 4)} if ap else None}
         del e1, fr1
+        # one frame of look-ahead: two one-frame windows on two HIP streams (frame t + 1's trunk beside frame t's; SAM in stream
+        # order; bit-identical results, tests/test_gpu_net.py::test_two_windows_on_two_streams_are_bit_identical) -- what
+        # `--frames-in-flight 1` runs by default (--windows 2)
+        f2, ms2, e2, fr2, _ = run_config(args, world, rank, dev, group, weights, 1, max(10, args.steps), min(args.warmup, 10), nwin=2)
+        res["one_frame_per_step"]["with_one_frame_of_lookahead"] = {
+            "value": round(f2, 2), "unit": "frames/s", "ms_per_frame": round(ms2 / 2, 4), "frames_resident": 2,
+            "whole_path_frac": round(f2 * gflop_frame / 1e3 / PEAK_BF16_TFLOPS, 4)}
+        del e2, fr2
     if rank == 0 and world == 1 and not args.no_miou:
         # five seeded 30-frame streams through the measured configuration; the +-0.1 bar applies to the MEAN delta (one stream's
         # delta is one draw of the bf16 rounding noise, tests/test_gpu_net.py::test_stream_miou_vs_reference_five_streams)
@@ -506,6 +567,11 @@ def main():
                 gate=("the +-0.1 bar is asserted on the MEAN over the streams (tests/test_gpu_net.py::test_stream_miou_vs_reference_five_streams); "
                       "a single 30-frame stream's delta is one draw of the bf16 storage noise (DESIGN.md 1, tests/golden/bf16_floor.json) and is "
                       "reported per stream with its own pass/fail; the fp32-exact mode holds +-0.01 on every stream (tests/test_gpu_exact.py)"))
+    if rank == 0 and world == 1 and not args.no_exact_mode:
+        # parity-grade throughput: the fp32-exact mode on the same stream (fp32x3 = fp32-grade products, fp32x2 = "bf16x3")
+        torch.cuda.empty_cache()
+        res["exact_mode"] = [exact_mode(dev, prec, fif, 4, H, W) for prec in ("fp32x2", "fp32x3")]
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_calibration:
         res["calibration"] = calibrate(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

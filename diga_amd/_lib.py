@@ -80,8 +80,8 @@ SIGNATURES = {
     "diga_preprocess_image": (_i, [_vp, _i, _vp, _i, _i, _i, _d, _d, _d, _i, _vp]),
     "diga_map_labels": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _vp]),
     "diga_stem_conv7x7s2_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "diga_bn_apply_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
-    "diga_bn_relu_maxpool_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "diga_bn_apply_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
+    "diga_bn_relu_maxpool_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "diga_split_planes_f32": (_i, [_vp, _vp, _i, _i64, _vp]),
     "diga_proto_pool_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "diga_proto_classify_fuse_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp]),

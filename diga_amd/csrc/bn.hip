@@ -307,10 +307,11 @@ __global__ __launch_bounds__(256) void bn_apply_f32_kernel(const float* __restri
                                                            const float* __restrict__ shift, const float* __restrict__ res,
                                                            const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                            float* __restrict__ out_f32, unsigned short* __restrict__ planes,
-                                                           int nplanes, int64_t total, int C, int relu) {
+                                                           int nplanes, int64_t total, int C, int relu, int64_t sample_elems) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)(i % C);
+  // sample_elems > 0: every sample (sample_elems consecutive elements) has its own affine [nsamples][C]
+  const int c = (int)(i % C) + (sample_elems > 0 ? (int)(i / sample_elems) * C : 0);
   float y = fmaf(raw[i], scale[c], shift[c]);
   if (MODE == 1) y += res[i];
   if (MODE == 2) y += fmaf(res[i], rscale[c], rshift[c]);
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void bn_apply_f32_kernel(const float* __restri
 __global__ __launch_bounds__(256) void bn_relu_maxpool_f32_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, float* __restrict__ out_f32,
                                                                   unsigned short* __restrict__ planes, int nplanes, int B, int H,
-                                                                  int W, int C, int Ho, int Wo) {
+                                                                  int W, int C, int Ho, int Wo, int per_sample) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)B * Ho * Wo * C;
   if (idx >= total) return;
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_f32_kernel(const float* _
   const int ow = (int)(pix % Wo);
   pix /= Wo;
   const int oh = (int)(pix % Ho), n = (int)(pix / Ho);
-  const float sc = scale[c], sh = shift[c];
+  const int ac = c + (per_sample ? n * C : 0);
+  const float sc = scale[ac], sh = shift[ac];
   float best = -INFINITY;
   for (int kh = 0; kh < 3; ++kh) {
     const int ih = oh * 2 - 1 + kh;
@@ -541,27 +543,30 @@ extern "C" int diga_bn_apply_nchw_f32(const float* x, const float* scale, const 
 
 extern "C" int diga_bn_apply_f32(const float* raw, const float* scale, const float* shift, const float* res, const float* res_scale,
                                  const float* res_shift, float* out_f32, void* out_planes, int nplanes, int64_t M, int C, int relu,
-                                 void* stream) {
+                                 int nsamples_affine, void* stream) {
   DIGA_CHECK_ARG(raw && scale && shift && (out_f32 || out_planes), "diga_bn_apply_f32: NULL pointer");
   DIGA_CHECK_ARG(M > 0 && C > 0 && (!out_planes || (nplanes >= 1 && nplanes <= 3)), "diga_bn_apply_f32: bad sizes / nplanes");
   DIGA_CHECK_ARG((res_scale == nullptr) == (res_shift == nullptr), "diga_bn_apply_f32: res_scale/res_shift go together");
   DIGA_CHECK_ARG(res != nullptr || res_scale == nullptr, "diga_bn_apply_f32: residual affine without residual");
+  DIGA_CHECK_ARG(nsamples_affine >= 0 && (nsamples_affine == 0 || M % nsamples_affine == 0),
+                 "diga_bn_apply_f32: M=%lld is not a whole number of %d samples", (long long)M, nsamples_affine);
+  const int64_t se = nsamples_affine > 0 ? M / nsamples_affine * C : 0;
   const int64_t total = M * C;
   const dim3 grid(cdiv(total, 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
   unsigned short* pl = (unsigned short*)out_planes;
   if (!res)
-    hipLaunchKernelGGL(bn_apply_f32_kernel<0>, grid, block, 0, st, raw, scale, shift, res, res_scale, res_shift, out_f32, pl, nplanes, total, C, relu);
+    hipLaunchKernelGGL(bn_apply_f32_kernel<0>, grid, block, 0, st, raw, scale, shift, res, res_scale, res_shift, out_f32, pl, nplanes, total, C, relu, se);
   else if (!res_scale)
-    hipLaunchKernelGGL(bn_apply_f32_kernel<1>, grid, block, 0, st, raw, scale, shift, res, res_scale, res_shift, out_f32, pl, nplanes, total, C, relu);
+    hipLaunchKernelGGL(bn_apply_f32_kernel<1>, grid, block, 0, st, raw, scale, shift, res, res_scale, res_shift, out_f32, pl, nplanes, total, C, relu, se);
   else
-    hipLaunchKernelGGL(bn_apply_f32_kernel<2>, grid, block, 0, st, raw, scale, shift, res, res_scale, res_shift, out_f32, pl, nplanes, total, C, relu);
+    hipLaunchKernelGGL(bn_apply_f32_kernel<2>, grid, block, 0, st, raw, scale, shift, res, res_scale, res_shift, out_f32, pl, nplanes, total, C, relu, se);
   DIGA_CHECK_LAUNCH("diga_bn_apply_f32");
   return DIGA_OK;
 }
 
 extern "C" int diga_bn_relu_maxpool_f32(const float* raw, const float* scale, const float* shift, float* out_f32, void* out_planes,
-                                        int nplanes, int B, int H, int W, int C, int Ho, int Wo, void* stream) {
+                                        int nplanes, int B, int H, int W, int C, int Ho, int Wo, int per_sample, void* stream) {
   DIGA_CHECK_ARG(raw && scale && shift && (out_f32 || out_planes), "diga_bn_relu_maxpool_f32: NULL pointer");
   DIGA_CHECK_ARG(B > 0 && H > 1 && W > 1 && C > 0 && (!out_planes || (nplanes >= 1 && nplanes <= 3)), "diga_bn_relu_maxpool_f32: bad dims");
   auto osz = [](int L) {
@@ -572,7 +577,7 @@ extern "C" int diga_bn_relu_maxpool_f32(const float* raw, const float* scale, co
   DIGA_CHECK_ARG(Ho == osz(H) && Wo == osz(W), "diga_bn_relu_maxpool_f32: output %dx%d does not match ceil-mode pooling of %dx%d", Ho, Wo, H, W);
   const int64_t total = (int64_t)B * Ho * Wo * C;
   hipLaunchKernelGGL(bn_relu_maxpool_f32_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, raw, scale, shift, out_f32,
-                     (unsigned short*)out_planes, nplanes, B, H, W, C, Ho, Wo);
+                     (unsigned short*)out_planes, nplanes, B, H, W, C, Ho, Wo, per_sample);
   DIGA_CHECK_LAUNCH("diga_bn_relu_maxpool_f32");
   return DIGA_OK;
 }

@@ -12,8 +12,10 @@ bit-exact, mIoU within 0.01) can be demonstrated end to end, not only stage by s
 * SAM: ``diga_proto_pool_f32`` / ``diga_proto_classify_fuse_f32`` on the fp32 features; head, labels, update, fusion and
   the tail are the product kernels unchanged (they are fp32 already).
 
-Batch semantics only (one batch of B samples per step, the reference's); no stream mode, no exchange.  Throughput is
-irrelevant here (6x the MFMA work, element-per-thread apply kernels).
+Batch semantics (one batch of B samples per step, the reference's) or, with stream=True, B consecutive batch-1 frames of
+a stream in flight (per-sample DAM statistics, SAM frame by frame in stream order: every frame bit-identical to its own
+batch-1 step, as Engine(stream=True)); no exchange.  Not tuned for speed (3x / 6x the MFMA work, element-per-thread apply
+kernels, per-frame SAM launches); bench.py reports what it runs at next to the product path ("exact_mode").
 """
 from __future__ import annotations
 
@@ -65,8 +67,9 @@ class ExactEngine(Engine):
     """Engine whose trunk, head and SAM run at fp32-grade precision (see the module docstring)."""
 
     def __init__(self, weights: ExactWeights, B: int, H: int, W: int, bn_lambda: float = 0.8, confidence_threshold: float = 0.9,
-                 conv_tile: int = 0):
-        super().__init__(weights, B, H, W, bn_lambda=bn_lambda, confidence_threshold=confidence_threshold, conv_tile=conv_tile)
+                 conv_tile: int = 0, stream: bool = False):
+        super().__init__(weights, B, H, W, bn_lambda=bn_lambda, confidence_threshold=confidence_threshold, conv_tile=conv_tile,
+                         stream=stream, fuse_apply=False)
         self.np_ = weights.nplanes
         dev, f32, bf = self.dev, torch.float32, torch.bfloat16
         n1, n2, n3 = B * self.h1 * self.w1, B * self.h2 * self.w2, B * self.h3 * self.w3
@@ -106,7 +109,7 @@ class ExactEngine(Engine):
 
     def _apply_x(self, raw, sc, sh, res, rsc, rsh, out_f32, out_planes, M, Cc, relu=1):
         call("diga_bn_apply_f32", _p(raw), _p(sc), _p(sh), _p(res), _p(rsc), _p(rsh), _p(out_f32), _p(out_planes), self.np_, M, Cc, relu,
-             _stream())
+             self.B if self.stream else 0, _stream())
 
     def _tapf(self, name, t, shape):
         if self.taps is not None:
@@ -125,7 +128,7 @@ class ExactEngine(Engine):
         sc, sh = self._finalize(bn, self.stem_units // B, self.h1 * self.w1)
         fcur, fnxt, pcur, pnxt = self.f_xa, self.f_xb, self.p_xa, self.p_xb
         call("diga_bn_relu_maxpool_f32", _p(self.f_stem), _p(sc), _p(sh), _p(fcur), _p(pcur), self.np_, B, self.h1, self.w1, 64,
-             self.h2, self.w2, _stream())
+             self.h2, self.w2, int(self.stream), _stream())
         self._tapf("maxpool", fcur, (B, self.h2, self.w2, 64))
         Hc, Wc, Cc = self.h2, self.w2, 64
         for li, (nb, pl, st, dil) in enumerate(zip(LAYERS, PLANES, STRIDES, DILATIONS), start=1):
@@ -163,7 +166,7 @@ class ExactEngine(Engine):
         self._conv_x("head", pcur, self.head_part, self.h, self.wd, FEAT_CH, self.h, self.wd, w.head_cout, 1, 1, False, None,
                      wgt=w.head_planes, stats=False, cout_pad=w.head_cpad)
         call("diga_head_tapsum_pseudo_label", _p(self.head_part), w.head_cpad, 18, self.head_dy, self.head_dx, _p(w.head_bias),
-             _p(self.logits), _p(self.labels), B, self.C, self.h, self.wd, self.threshold, 0, _stream())
+             _p(self.logits), _p(self.labels), B, self.C, self.h, self.wd, self.threshold, 2 * self.hw if self.stream else 0, _stream())
         return self.feat_f32, self.logits
 
     def sam_fuse(self, y: torch.Tensor, cfg):
@@ -172,11 +175,26 @@ class ExactEngine(Engine):
         assert y.shape[0] == B and y.dtype in (torch.int64, torch.int32) and y.is_contiguous()
         rho = float(cfg["proto_rho"])
         pl, fl = float(cfg["proto_lambda"]), float(cfg["fusion_lambda"])
+        coef = (float(np.float32(pl)), float(np.float32(1 - pl)), float(np.float32(fl)), float(np.float32(1 - fl)))
+        hw = self.hw
+        if self.stream:
+            # labels [frame][pseudo | gt][hw]; every frame takes the batch-1 launches in stream order (the running prototypes of
+            # frame t feed frame t + 1, ttda:1702-1705)
+            call("diga_nearest_down_labels", _p(y), int(y.dtype == torch.int64), _p(self.labels[hw:]), B, y.shape[1], y.shape[2], self.h,
+                 self.wd, 2 * hw, _stream())
+            for f in range(B):
+                feat = self.feat_f32[f * hw * FEAT_CH:(f + 1) * hw * FEAT_CH]
+                call("diga_proto_pool_f32", _p(feat), _p(self.labels[f * 2 * hw:]), 2, hw, Cn, FEAT_CH, _p(self.pool_work), _p(self.pool_sums),
+                     _p(self.pool_counts), _stream())
+                call("diga_proto_update", _p(self.pool_sums), _p(self.pool_counts), Cn, FEAT_CH, _p(self.inst_proto), _p(self.inst_flag),
+                     _p(self.run_proto), _p(self.run_flag), _p(self.state_flag), float(np.float32(1 - rho)), float(np.float32(rho)), _stream())
+                call("diga_proto_classify_fuse_f32", _p(feat), _p(self.logits[f]), _p(self.inst_proto), _p(self.inst_flag), _p(self.run_proto),
+                     _p(self.run_flag), _p(self.probs[f]), _p(self.pcf_work), 1, Cn, hw, FEAT_CH, 1.0, *coef, _stream())
+            return self.probs
         call("diga_nearest_down_labels", _p(y), int(y.dtype == torch.int64), _p(self.labels[self.P:]), B, y.shape[1], y.shape[2], self.h,
              self.wd, 0, _stream())
         call("diga_proto_pool_f32", _p(self.feat_f32), _p(self.labels), 2, self.P, Cn, FEAT_CH, _p(self.pool_work), _p(self.pool_sums),
              _p(self.pool_counts), _stream())
-        coef = (float(np.float32(pl)), float(np.float32(1 - pl)), float(np.float32(fl)), float(np.float32(1 - fl)))
         call("diga_proto_update", _p(self.pool_sums), _p(self.pool_counts), Cn, FEAT_CH, _p(self.inst_proto), _p(self.inst_flag),
              _p(self.run_proto), _p(self.run_flag), _p(self.state_flag), float(np.float32(1 - rho)), float(np.float32(rho)), _stream())
         call("diga_proto_classify_fuse_f32", _p(self.feat_f32), _p(self.logits), _p(self.inst_proto), _p(self.inst_flag), _p(self.run_proto),

@@ -396,13 +396,15 @@ int diga_map_labels(const void* ids, int ids_kind, const int32_t* lut, int nlut,
 int diga_stem_conv7x7s2_f32(const float* x, const float* wgt, float* out, float* stat_slab,
                             const float* stat_shift, int B, int H, int W, void* stream);
 /* diga_bn_apply on fp32 data: raw, res fp32 [M][C]; y -> out_f32 (fp32 [M][C], may be NULL) and/or out_planes (bf16
- * [nplanes][M][C], may be NULL): plane 0 = bf16(y), plane q = bf16(y - planes before it) (adaptseg:86-100). */
+ * [nplanes][M][C], may be NULL): plane 0 = bf16(y), plane q = bf16(y - planes before it) (adaptseg:86-100).
+ * nsamples_affine as diga_bn_apply (> 0: per-sample affines [nsamples][C]: frames of a stream in flight). */
 int diga_bn_apply_f32(const float* raw, const float* scale, const float* shift, const float* res,
                       const float* res_scale, const float* res_shift, float* out_f32, void* out_planes,
-                      int nplanes, int64_t M, int C, int relu, void* stream);
-/* diga_bn_relu_maxpool on fp32 data (adaptseg:179-181), outputs as diga_bn_apply_f32. */
+                      int nplanes, int64_t M, int C, int relu, int nsamples_affine, void* stream);
+/* diga_bn_relu_maxpool on fp32 data (adaptseg:179-181), outputs as diga_bn_apply_f32; per_sample as diga_bn_relu_maxpool. */
 int diga_bn_relu_maxpool_f32(const float* raw, const float* scale, const float* shift, float* out_f32,
-                             void* out_planes, int nplanes, int B, int H, int W, int C, int Ho, int Wo, void* stream);
+                             void* out_planes, int nplanes, int B, int H, int W, int C, int Ho, int Wo, int per_sample,
+                             void* stream);
 /* x fp32 [n] -> bf16 planes [nplanes][n] whose sum is x (weights / inputs of the verification mode). */
 int diga_split_planes_f32(const float* x, void* planes, int nplanes, int64_t n, void* stream);
 /* diga_proto_pool / diga_proto_classify_fuse with fp32 features [P][CH] (same work sizes, same arithmetic order). */

@@ -250,6 +250,37 @@ def test_end_to_end_vs_reference_full_res(diga, gold_full):
     assert np.abs(np.array(mious) - gold_full["miou"]).max() <= 0.1
 
 
+def test_end_to_end_vs_reference_hires_2048x1024(diga):
+    """BASELINE configs[3]'s resolution against the reference: two 2048x1024 frames, B = 1 (the 129x257 feature grid), at the
+    bf16-storage floor (the strict comparison of the same fixture: tests/test_gpu_exact.py::test_exact_hires_2048x1024_vs_reference)."""
+    from conftest import load_golden
+    g = load_golden("net_hires.npz")
+    m = diga
+    _MARGINAL.clear()
+    if hasattr(m, "classifier_running_proto"):
+        del m.classifier_running_proto
+    m.test_acc[0].reset()
+    stats = []
+    sub = (slice(None), slice(None), slice(None, None, 2), slice(None, None, 2))
+    for t in range(2):
+        x, y = synth.synth_frame(t, 1, 1024, 2048)
+        m.test_step((torch.from_numpy(x), torch.from_numpy(y), None, None), t)
+        eng = m._last_engine
+        torch.cuda.synchronize()
+        key = lambda k: f"hr_{t}_{k}"
+        ref_logits = g[key("logits_sub")]
+        pl = eng.labels[:eng.P].cpu().numpy().reshape(g[key("pseudo")].shape)
+        stats.append(dict(logit_err=float(np.abs(eng.logits.cpu().numpy()[sub] - ref_logits).max() / (ref_logits.max() - ref_logits.min())),
+                          pseudo_agree=float((pl == g[key("pseudo")]).mean()),
+                          pred_agree=float((eng.pred.cpu().numpy() == g[key("pred")]).mean()),
+                          rflag_equal=_flags_equal_up_to_marginal(m.classifier_running_proto_exists_flag.cpu().numpy(), g[key("rflag")],
+                                                                  pl, g[key("pseudo")])))
+    mious = [float(m.test_acc[0].compute()), float(m.test_acc[0].compute_iou("16")), float(m.test_acc[0].compute_iou("13"))]
+    print(stats, mious, g["hr_miou"])
+    _check_against_floor(stats, None)
+    assert np.abs(np.array(mious) - g["hr_miou"]).max() <= 0.1
+
+
 def test_stream_miou_vs_reference_five_streams(weights):
     """BASELINE.json's metric, second half ("mIoU delta vs ref") for the bf16 PRODUCT path: five 30-frame batch-1 streams
     (frame seeds 0..4) through the configuration bench.py measures (2 windows x 15 frames in flight) against the reference's
