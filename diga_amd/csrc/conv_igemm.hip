@@ -805,9 +805,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
 // kernel: outputs and slab are bit-identical (tests/test_gpu_kernels.py).
 // Grid = (unit groups) x (Cout / 128) blocks; the slices of one unit group get consecutive logical ids = one XCD, whose L2
 // serves the re-reads of the group's A rows.
-template <int KC>
+// Tile id 92 = the same kernel with 64-column slices for K = 512 (layer4's conv3, layer3's downsample): the slice is again 64 KiB
+// of LDS, a wave's A fragments are 128 registers and its MFMA work per unit (128) equals that of a K = 256, 128-column unit, while
+// the epilogue -- statistics, staging and stores are what a unit's time is made of -- covers half as many accumulators.
+template <int KC, int BN>
 __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, int units_total, int units_per_group) {
-  constexpr int BN = 128, NTW = BN / 16, KS = KC / 32;
+  constexpr int NTW = BN / 16, KS = KC / 32;
+  constexpr int LPR = BN / 8, RPS = 64 / LPR, NST = 32 / RPS;   // output stores: lanes per row, rows per store instruction, stores per unit
+  constexpr int SQ = BN / 4;                                    // statistics read-back: lanes per row of the unit's [2][BN] words
   constexpr int ROWB = KC * 2, B_BYTES = BN * ROWB;
   constexpr int SW_LD = BN + 8;                                // a wave's staging tile: 32 rows, 16 bytes of padding per row,
   constexpr int SW_BYTES = 32 * SW_LD * 2 + 2 * BN * 4;        // + the unit's 2 x 128 statistics words (one 16-byte store per lane)
@@ -961,19 +966,21 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
     const unsigned long long c2 = clock64();
 #endif
     const size_t orow = (size_t)n_img * p.hw + ubase;
-    u32x4 ov[8];
+    u32x4 ov[NST];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ov[i] = *reinterpret_cast<const u32x4*>(sW + (i * 4 + (lane >> 4)) * SW_LD + (lane & 15) * 8);
-    const f32x4 sv = *reinterpret_cast<const f32x4*>(sS + lane * 4);          // row lane >> 5, columns 4 (lane & 31) .. + 3
-    *reinterpret_cast<f32x4*>(&p.slab[((size_t)u * 2 + (lane >> 5)) * p.Cout + n0 + (lane & 31) * 4]) = sv;
-    unsigned short* const orp = out + (orow + (lane >> 4)) * p.Cout + n0 + (lane & 15) * 8;
+    for (int i = 0; i < NST; ++i) ov[i] = *reinterpret_cast<const u32x4*>(sW + (i * RPS + lane / LPR) * SW_LD + (lane % LPR) * 8);
+    if (lane < 2 * SQ) {                                                       // row lane / SQ, columns 4 (lane % SQ) .. + 3
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(sS + lane * 4);
+      *reinterpret_cast<f32x4*>(&p.slab[((size_t)u * 2 + lane / SQ) * p.Cout + n0 + (lane % SQ) * 4]) = sv;
+    }
+    unsigned short* const orp = out + (orow + lane / LPR) * p.Cout + n0 + (lane % LPR) * 8;
     if (full) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(ov[i], reinterpret_cast<u32x4*>(orp + (size_t)i * 4 * p.Cout));
+      for (int i = 0; i < NST; ++i) __builtin_nontemporal_store(ov[i], reinterpret_cast<u32x4*>(orp + (size_t)i * RPS * p.Cout));
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (ubase + i * 4 + (lane >> 4) < p.hw) __builtin_nontemporal_store(ov[i], reinterpret_cast<u32x4*>(orp + (size_t)i * 4 * p.Cout));
+      for (int i = 0; i < NST; ++i)
+        if (ubase + i * RPS + lane / LPR < p.hw) __builtin_nontemporal_store(ov[i], reinterpret_cast<u32x4*>(orp + (size_t)i * RPS * p.Cout));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging tile has been read: the next unit may overwrite it
     __builtin_amdgcn_wave_barrier();
@@ -990,34 +997,40 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
 #endif
 }
 
-int launch_ws(const diga_conv_desc* d, const ConvKParams& p, int epi, hipStream_t st) {
+int launch_ws(const diga_conv_desc* d, const ConvKParams& p, int epi, int bn, hipStream_t st) {
+  const int id = bn == 128 ? 91 : 92;
   DIGA_CHECK_ARG(d->ntaps == 1 && d->stride == 1 && d->dy[0] == 0 && d->dx[0] == 0 && d->H == d->Ho && d->W == d->Wo,
-                 "diga_conv_igemm_bf16: tile 91 (weights-stationary) is for 1x1 stride-1 convolutions");
-  DIGA_CHECK_ARG((d->Cin == 64 || d->Cin == 128 || d->Cin == 256) && d->Cout % 128 == 0 && d->cout_pad == d->Cout,
-                 "diga_conv_igemm_bf16: tile 91 needs Cin in {64, 128, 256} and Cout %% 128 == 0 (got %d -> %d)", d->Cin, d->Cout);
+                 "diga_conv_igemm_bf16: tile %d (weights-stationary) is for 1x1 stride-1 convolutions", id);
+  if (bn == 128)
+    DIGA_CHECK_ARG((d->Cin == 64 || d->Cin == 128 || d->Cin == 256) && d->Cout % 128 == 0 && d->cout_pad == d->Cout,
+                   "diga_conv_igemm_bf16: tile 91 needs Cin in {64, 128, 256} and Cout %% 128 == 0 (got %d -> %d)", d->Cin, d->Cout);
+  else
+    DIGA_CHECK_ARG(d->Cin == 512 && d->Cout % 64 == 0 && d->cout_pad == d->Cout,
+                   "diga_conv_igemm_bf16: tile 92 needs Cin = 512 and Cout %% 64 == 0 (got %d -> %d)", d->Cin, d->Cout);
   DIGA_CHECK_ARG(epi == EPI_BF16_STATS && p.nterms == 1 && d->splitk == 1 && p.fin_ticket == nullptr,
-                 "diga_conv_igemm_bf16: tile 91 has the trunk epilogue only (bf16 output + statistics)");
-  const int units_total = d->B * p.units_per_sample, nslices = d->Cout / 128;
+                 "diga_conv_igemm_bf16: tile %d has the trunk epilogue only (bf16 output + statistics)", id);
+  const int units_total = d->B * p.units_per_sample, nslices = d->Cout / bn;
   // one block per CU (its LDS): as many unit groups as fill the chip once, at least 8 units (one per wave) per group
   int groups = 256 / nslices;
   if (groups < 1) groups = 1;
   if (groups > cdiv(units_total, 8)) groups = cdiv(units_total, 8);
   const int upg = cdiv(units_total, groups);
   groups = cdiv(units_total, upg);
-  const int smem = 128 * d->Cin * 2 + 8 * (32 * (128 + 8) * 2 + 2 * 128 * 4);
+  const int smem = bn * d->Cin * 2 + 8 * (32 * (bn + 8) * 2 + 2 * bn * 4);
   dim3 grid(groups * nslices), block(512);
-#define DIGA_WS_LAUNCH(KC)                                                                                              \
+#define DIGA_WS_LAUNCH(KC, BN)                                                                                          \
   {                                                                                                                     \
     static std::once_flag once;                                                                                         \
     std::call_once(once, [&] {                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                128 * KC * 2 + 8 * (32 * (128 + 8) * 2 + 2 * 128 * 4));                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_kernel<KC, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                BN * KC * 2 + 8 * (32 * (BN + 8) * 2 + 2 * BN * 4));                                                    \
     });                                                                                                                 \
-    hipLaunchKernelGGL(conv1x1_ws_kernel<KC>, grid, block, smem, st, p, units_total, upg);                              \
+    hipLaunchKernelGGL((conv1x1_ws_kernel<KC, BN>), grid, block, smem, st, p, units_total, upg);                        \
   }
-  if (d->Cin == 64) DIGA_WS_LAUNCH(64)
-  else if (d->Cin == 128) DIGA_WS_LAUNCH(128)
-  else DIGA_WS_LAUNCH(256)
+  if (d->Cin == 64) DIGA_WS_LAUNCH(64, 128)
+  else if (d->Cin == 128) DIGA_WS_LAUNCH(128, 128)
+  else if (d->Cin == 256) DIGA_WS_LAUNCH(256, 128)
+  else DIGA_WS_LAUNCH(512, 64)
 #undef DIGA_WS_LAUNCH
   return DIGA_OK;
 }
@@ -1047,8 +1060,8 @@ const TileCfg kTiles[] = {{1, 128, 128, 4}, {11, 128, 128, 3}, {21, 128, 128, 2}
                           {61, 128, 128, 2, 32, false}, {64, 64, 128, 2, 32, false}, {66, 256, 128, 2, 32, true}, {67, 128, 256, 2, 32, true},
                           // ids 76 / 77: the shapes of 66 / 67 without interleaved issue -- the fused-input kernels only
                           {76, 256, 128, 2, 32, false}, {77, 128, 256, 2, 32, false},
-                          // id 91: conv1x1_ws_kernel (weights-stationary 1x1, Cin <= 256); BM = its 32-row units
-                          {91, 32, 128, 1, 64, false}};
+                          // id 91: conv1x1_ws_kernel (weights-stationary 1x1, Cin <= 256); BM = its 32-row units; id 92: Cin = 512, 64-column slices
+                          {91, 32, 128, 1, 64, false}, {92, 32, 64, 1, 64, false}};
 
 const TileCfg* find_tile(int id) {
   for (const auto& t : kTiles)
@@ -1225,8 +1238,8 @@ int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out
     DIGA_CHECK_LAUNCH("diga_conv_igemm_bf16_fused_in");
     return DIGA_OK;
   }
-  if (t->id == 91) {
-    if (int e91 = launch_ws(d, p, epi, st)) return e91;
+  if (t->id == 91 || t->id == 92) {
+    if (int e91 = launch_ws(d, p, epi, t->BN, st)) return e91;
     DIGA_CHECK_LAUNCH("diga_conv_igemm_bf16");
     return DIGA_OK;
   }

@@ -443,7 +443,9 @@ class Engine:
     TILE_CANDIDATES = {76: 128, 77: 256, 23: 64, 13: 64, 22: 64, 12: 64, 24: 128, 14: 128, 21: 128, 26: 128, 16: 128, 27: 256, 17: 256, 28: 256,
                        33: 64, 32: 64, 34: 128, 31: 128, 36: 128, 37: 256, 38: 256,
                        46: 128, 47: 256, 48: 256, 56: 128, 57: 256, 58: 256, 61: 128, 64: 128, 66: 128, 67: 256,
-                       91: 128}   # id -> N tile (91: the weights-stationary 1x1 kernel; refused, and skipped, for other convs)
+                       91: 128}   # id -> N tile (91: the weights-stationary 1x1 kernel; refused, and skipped, for other convs.  Its K = 512
+    # form, id 92, is built and bit-identical but loses to the tiled kernels on every K = 512 shape of the net -- 454 vs 366 us on
+    # layer4.conv3, 237 vs 197 us on layer3's downsample at 15 frames, profiles/r3_tile92_sweep.log -- so it is not a candidate)
 
     def _tune(self, d, launch, reps=3):
         best, best_t = 0, float("inf")

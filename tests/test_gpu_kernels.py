@@ -131,7 +131,8 @@ def test_conv_results_do_not_depend_on_tile_or_batch():
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 13, 21, 256, 256), (2, 9, 17, 128, 512), (1, 33, 65, 64, 256), (4, 7, 5, 256, 1024),
-                                            (6, 65, 129, 256, 1024), (2, 129, 257, 64, 256), (5, 65, 129, 128, 512)])
+                                            (6, 65, 129, 256, 1024), (2, 129, 257, 64, 256), (5, 65, 129, 128, 512),
+                                            (3, 13, 21, 512, 2048), (4, 65, 129, 512, 1024), (1, 7, 5, 512, 64)])
 def test_weights_stationary_1x1_is_bit_identical(B, H, W, Cin, Cout):
     """Tile id 91 (conv1x1_ws_kernel: weights resident in LDS, one wave per 32-row statistics unit) against the tiled kernel:
     raw output and statistics slab bit-identical, ragged last unit of every sample included; shapes it does not cover are
@@ -152,19 +153,20 @@ def test_weights_stationary_1x1_is_bit_identical(B, H, W, Cin, Cout):
         torch.cuda.synchronize()
         return out.view(torch.int16).cpu(), slab.cpu()
 
+    ws = 92 if Cin == 512 else 91   # 92: the K = 512 form with 64-column slices
     o0, s0 = run(23)
     for rep in range(3):            # the kernel counts its own memory operations: screen for a wait that is too lenient
-        o1, s1 = run(91)
+        o1, s1 = run(ws)
         assert not torch.isnan(s1).any()
         assert torch.equal(o0, o1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32)), rep
     ref = F.conv2d(x, wt)
     assert rel_err(from_nhwc_bf16(o1.view(torch.bfloat16).to(DEV), (B, H, W, Cout)), bf16_round(ref)) <= BF16_TOL
     # a 3x3 conv / Cin = 512 has no weights-stationary kernel: refused, not silently mis-run
-    d = conv_desc(B, H, W, Cin, Cout, 1, True, 1, tile=91)
+    d = conv_desc(B, H, W, Cin, Cout, 1, True, 1, tile=ws)
     w9 = torch.zeros(Cout * 9 * Cin, dtype=torch.bfloat16, device=DEV)
     out = torch.zeros(B * H * W * Cout, dtype=torch.bfloat16, device=DEV)
     slab = torch.zeros(call("diga_conv_stat_units", C.byref(d)) * 2 * Cout, dtype=torch.float32, device=DEV)
-    with pytest.raises(Exception, match="tile 91"):
+    with pytest.raises(Exception, match=f"tile {ws}"):
         call("diga_conv_igemm_bf16", C.byref(d), P(xin), P(w9), P(out), P(slab), P(shift), stream())
 
 
