@@ -136,13 +136,24 @@ def dam_affine(x_raw, running_mean, running_var, weight, bias, lam, eps=1e-5):
     return sc, bias - mean * sc
 
 
-def net_forward_feat_bf16(p: dict, x: torch.Tensor, lam: float = 0.8, taps: dict | None = None):
+def net_forward_feat_bf16(p: dict, x: torch.Tensor, lam: float = 0.8, taps: dict | None = None, keep_fp32=()):
     """The same network with the GPU pipeline's *storage* precision emulated: conv weights (except the
     fp32 stem) and every stored activation are rounded to bf16, all arithmetic stays fp32, and the DAM
     statistics are taken from the un-rounded fp32 conv outputs (as the conv epilogue does).  This is
     the oracle for end-to-end parity of the bf16 path: it differs from ``net_forward_feat`` only by
-    rounding, and the GPU differs from it only by fp32 summation order."""
-    r = bf16_round
+    rounding, and the GPU differs from it only by fp32 summation order.
+
+    keep_fp32: which classes of stored tensors are NOT rounded (the study of what sets the bf16 floor,
+    tests/golden/make_bf16_switch_study.py): "residual" = the block input / output stream, "raw" = raw
+    conv outputs, "act" = the normalised activations between the convs of a block (and the pooled stem
+    output), "head_in" = only the layer4 output that feeds the head and SAM, "weights" = conv weights."""
+    keep = set(keep_fp32)
+    assert keep <= {"residual", "raw", "act", "head_in", "weights"}, keep
+    ident = lambda t: t      # noqa: E731
+    r_res = ident if "residual" in keep else bf16_round
+    r_raw = ident if "raw" in keep else bf16_round
+    r_act = ident if "act" in keep else bf16_round
+    r_w = ident if "weights" in keep else bf16_round
 
     def aff(prefix, raw):
         return dam_affine(raw, p[prefix + ".running_mean"], p[prefix + ".running_var"], p[prefix + ".weight"],
@@ -154,32 +165,37 @@ def net_forward_feat_bf16(p: dict, x: torch.Tensor, lam: float = 0.8, taps: dict
     raw = F.conv2d(x, p["conv1.weight"], stride=2, padding=3)
     sc, sh = aff("bn1", raw)
     if taps is not None:
-        taps["conv1"] = r(raw)
-    cur = r(F.max_pool2d(torch.relu(app(r(raw), sc, sh)), 3, 2, 1, ceil_mode=True))
+        taps["conv1"] = r_raw(raw)
+    cur = r_res(F.max_pool2d(torch.relu(app(r_raw(raw), sc, sh)), 3, 2, 1, ceil_mode=True))
     if taps is not None:
         taps["maxpool"] = cur
+    nblocks = sum(LAYERS)
+    done = 0
     for li, (nb, st, dil) in enumerate(zip(LAYERS, STRIDES, DILATIONS), start=1):
         for b in range(nb):
             pre = f"layer{li}.{b}"
             s = st if b == 0 else 1
-            raw1 = F.conv2d(cur, r(p[pre + ".conv1.weight"]), stride=s)
+            raw1 = F.conv2d(cur, r_w(p[pre + ".conv1.weight"]), stride=s)
             sc, sh = aff(pre + ".bn1", raw1)
-            a1 = r(torch.relu(app(r(raw1), sc, sh)))
-            raw2 = F.conv2d(a1, r(p[pre + ".conv2.weight"]), padding=dil, dilation=dil)
+            a1 = r_act(torch.relu(app(r_raw(raw1), sc, sh)))
+            raw2 = F.conv2d(a1, r_w(p[pre + ".conv2.weight"]), padding=dil, dilation=dil)
             sc, sh = aff(pre + ".bn2", raw2)
-            a2 = r(torch.relu(app(r(raw2), sc, sh)))
-            raw3 = F.conv2d(a2, r(p[pre + ".conv3.weight"]))
+            a2 = r_act(torch.relu(app(r_raw(raw2), sc, sh)))
+            raw3 = F.conv2d(a2, r_w(p[pre + ".conv3.weight"]))
             sc3, sh3 = aff(pre + ".bn3", raw3)
             if b == 0:
-                rawd = F.conv2d(cur, r(p[pre + ".downsample.0.weight"]), stride=s)
+                rawd = F.conv2d(cur, r_w(p[pre + ".downsample.0.weight"]), stride=s)
                 scd, shd = aff(pre + ".downsample.1", rawd)
-                res = app(r(rawd), scd, shd)
+                res = app(r_raw(rawd), scd, shd)
             else:
                 res = cur
-            cur = r(torch.relu(app(r(raw3), sc3, sh3) + res))
+            done += 1
+            last = done == nblocks
+            out = torch.relu(app(r_raw(raw3), sc3, sh3) + res)
+            cur = out if (last and "head_in" in keep) else r_res(out)
             if taps is not None:
                 taps[pre] = cur
-    hp = {k: (r(v) if k.endswith("weight") else v) for k, v in p.items() if k.startswith("layer6.")}
+    hp = {k: (r_w(v) if k.endswith("weight") else v) for k, v in p.items() if k.startswith("layer6.")}
     return cur, head_logits(hp, cur)
 
 
@@ -280,9 +296,12 @@ def fuse(multi_pred, logits, fusion_lambda):
     return multi_pred * fusion_lambda + logits.softmax(1) * (1 - fusion_lambda)
 
 
-def forward_and_adapt(p, state: SamState, x, y, cfg, info: dict | None = None, bf16: bool = False):
+def forward_and_adapt(p, state: SamState, x, y, cfg, info: dict | None = None, bf16: bool = False, keep_fp32=()):
     """ttda:1623-1645 (without the .cpu()).  bf16=True uses the storage-precision emulation of the GPU path."""
-    feat, logits = (net_forward_feat_bf16 if bf16 else net_forward_feat)(p, x, cfg["bn_lambda"])
+    if bf16:
+        feat, logits = net_forward_feat_bf16(p, x, cfg["bn_lambda"], keep_fp32=keep_fp32)
+    else:
+        feat, logits = net_forward_feat(p, x, cfg["bn_lambda"])
     if info is not None:
         info.update(feature=feat, logits=logits)
     return fuse(multi_proto_label(state, feat, logits, y, cfg, info), logits, cfg["fusion_lambda"])
