@@ -18,7 +18,7 @@ def _worker(rank, world, port, q, k):
     os.makedirs("gpurun_out", exist_ok=True)
     log = open(f"gpurun_out/dist_rank{rank}.log", "w")
     try:
-        (_worker_oneshot if k == 100 else _worker_oneshot_stream if k == 101 else _worker_late_peer if k == 102 else
+        (_worker_oneshot if k == 100 else _worker_four_ranks if k == 104 else _worker_oneshot_stream if k == 101 else _worker_late_peer if k == 102 else
          _worker_missing_peer if k == 103 else _worker_b8 if k == 8 else _worker_windows if k < 0 else _worker_stream if k > 1 else _worker_body)(rank, world, port, q, log, k)
     except Exception:
         traceback.print_exc(file=log)
@@ -187,6 +187,32 @@ def _worker_oneshot_stream(rank, world, port, q, log, k):
         pass
 
 
+def _worker_four_ranks(rank, world, port, q, log, k):
+    """Global batch 4 on FOUR ranks through the fused exchange (rank-order sums over more than two contributions)."""
+    import torch.distributed as dist
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
+    eng = Engine(w, 1, H, W, group=dist.group.WORLD, oneshot=True)
+    out = []
+    for t in range(NF):
+        x, y = synth.synth_frame(t, world, H, W)
+        probs = eng.forward_and_adapt(torch.from_numpy(x[rank:rank + 1]).cuda(), torch.from_numpy(y[rank:rank + 1]).cuda(), CFG)
+        torch.cuda.synchronize()
+        eng.check_exchange()
+        out.append(dict(probs=probs.cpu().numpy(), logits=eng.logits.cpu().numpy(), scale=eng.scale.cpu().numpy(), shift=eng.shift.cpu().numpy(),
+                        run=eng.run_proto.cpu().numpy(), rflag=eng.run_flag.cpu().numpy(), launches=eng.exchange_launches))
+    dist.barrier()
+    eng.close()
+    q.put((rank, out))
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
 def _worker_late_peer(rank, world, port, q, log, k):
     """A peer that arrives 2 s late is waited for (the wait is bounded by wall-clock time, 10 s here), not an error."""
     import time
@@ -312,12 +338,12 @@ def _worker_windows(rank, world, port, q, log, k):
         pass
 
 
-def _run_ranks(k):
+def _run_ranks(k, world=2):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + (os.getpid() + 7 * k) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, k)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, k)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=90) for _ in procs)
@@ -477,6 +503,34 @@ def test_two_ranks_fused_exchange_stream_of_global_batches():
     ref_run = eng.run_proto.cpu().numpy()
     assert np.array_equal(res[0]["run"], res[1]["run"]) and np.array_equal(res[0]["rflag"], eng.run_flag.cpu().numpy())
     assert np.abs(res[0]["run"] - ref_run).max() <= 1e-5 * np.abs(ref_run).max()
+
+
+def test_four_ranks_fused_exchange_reproduces_batch4():
+    """World size 4 (four processes on this GPU): the DAM scale / shift of all 104 layers, the logits, the probabilities and the
+    replicated SAM state are BIT-IDENTICAL on every rank (rank-order sums); against the single-process batch-4 engine the group
+    sums are associated differently (per-rank fp64 partials vs one pass over all units), so scale / shift agree to fp32 rounding
+    -- in practice bit for bit -- and the logits to the bf16 re-rounding that a last-bit change of an affine can cause."""
+    from diga_amd import synth
+    from diga_amd.engine import Engine, NetWeights
+    res = _run_ranks(104, world=4)
+    w = NetWeights(synth.synth_params(0), torch.device("cuda:0"))
+    eng = Engine(w, 4, H, W)
+    for t in range(NF):
+        x, y = synth.synth_frame(t, 4, H, W)
+        probs = eng.forward_and_adapt(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), CFG)
+        torch.cuda.synchronize()
+        sc_ref, sh_ref = eng.scale.cpu().numpy(), eng.shift.cpu().numpy()
+        lg_ref = eng.logits.cpu().numpy()
+        for r in range(4):
+            got = res[r][t]
+            assert got["launches"] == 106
+            assert np.array_equal(got["scale"], res[0][t]["scale"]) and np.array_equal(got["shift"], res[0][t]["shift"]), (t, r)
+            assert np.array_equal(got["run"], res[0][t]["run"]) and np.array_equal(got["rflag"], eng.run_flag.cpu().numpy()), (t, r)
+            assert np.abs(got["scale"] - sc_ref).max() <= 1e-6 * np.abs(sc_ref).max(), (t, r)
+            assert np.abs(got["logits"][0] - lg_ref[r]).max() <= 0.02 * (lg_ref.max() - lg_ref.min()), (t, r)
+            assert np.array_equal(np.isnan(got["probs"][0]), np.isnan(probs.cpu().numpy()[r]))
+        print("frame", t, "scale bit-identical to the single-process batch:", bool(np.array_equal(res[0][t]["scale"], sc_ref)),
+              "logits:", bool(all(np.array_equal(res[r][t]["logits"][0], lg_ref[r]) for r in range(4))))
 
 
 def test_oneshot_waits_for_a_late_peer():
