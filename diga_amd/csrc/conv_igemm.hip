@@ -319,7 +319,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
         if (i < lo || i >= hi) continue;
+#ifdef DIGA_EXP_SKIPA   /* experiment only (profiles/experiments/skipa): 2 of 3 taps fetch the zero page instead of their A rows */
+        const bool ok = (unsigned)(ih0[i] + dy) < (unsigned)p.H && (unsigned)(iw0[i] + dx) < (unsigned)p.W && (p.ntaps == 1 || dx == 0);
+#else
         const bool ok = (unsigned)(ih0[i] + dy) < (unsigned)p.H && (unsigned)(iw0[i] + dx) < (unsigned)p.W;
+#endif
         const unsigned short* src = ok ? in + (pixoff[i] + tapoff) : zero;
         __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(dA + i * NW * 1024), 16, 0, 0);
       }
