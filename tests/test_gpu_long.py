@@ -95,3 +95,88 @@ def test_long_multires_stream_bf16_path(synth_params_np):
     assert all(r["flags_equal"] for r in rows[5:])
     assert worst["hist_moved"] <= 0.06 and rows[-1]["hist_moved"] <= 0.01, (worst, rows[-1])
     assert rows[-1]["miou_delta"] <= 0.25 and max(r["miou_delta"] for r in late) <= 0.5, (worst, rows[-1])
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# One evaluation-length stream: 500 batch-1 frames of 1024x512 (GTA5 -> Cityscapes val has 500 images, README.md:241-243),
+# tests/golden/net_eval500.npz: the reference's cumulative confusion matrix / mIoU / prototype norms every 50 frames.
+# ------------------------------------------------------------------------------------------------------------------------
+def _eval500_checkpoints(step_fn, g, per_step):
+    """Drive `step_fn(list of (x, y) frames)` over the stream in steps of `per_step` frames (a divisor of the 50-frame checkpoint
+    spacing); after every 50 frames yield (frames so far, the checkpoint's reference entries)."""
+    n, every = int(g["ev_frames"]), int(g["ev_every"])
+    assert every % per_step == 0
+    for t0 in range(0, n, per_step):
+        step_fn([synth.synth_frame(t, 1, 512, 1024) for t in range(t0, t0 + per_step)])
+        done = t0 + per_step
+        if done % every == 0:
+            yield done, {k: g[f"ev_{done}_{k}"] for k in ("hist", "miou", "run_norm", "rflag", "nan_pixels")}
+
+
+@pytest.fixture(scope="module")
+def weights(synth_params_np):
+    from diga_amd.engine import NetWeights
+    return NetWeights(synth_params_np, torch.device("cuda:0"))
+
+
+def test_eval_length_stream_500_frames_bf16_path(weights):
+    """The bf16 PRODUCT path on ONE stream of realistic length, through the bench's configuration (two windows of frames in
+    flight, results bit-identical to one-frame steps): mIoU-19/16/13 within the north star's +-0.1 of the reference at 500
+    frames -- a single stream, no averaging over draws: over 500 frames the storage noise of the individual frames averages out."""
+    from diga_amd.pipeline import StreamWindows
+    g = load_golden("net_eval500.npz")
+    K = 25
+    sw = StreamWindows(weights, K, 2, 512, 1024, bn_lambda=CFG["bn_lambda"], autotune=False)
+
+    def step(frames):
+        wins = []
+        for w in range(2):
+            fr = frames[w * K:(w + 1) * K]
+            wins.append((torch.from_numpy(np.concatenate([a for a, _ in fr])).cuda(), torch.from_numpy(np.concatenate([b for _, b in fr])).cuda()))
+        sw.step(wins, CFG)
+        torch.cuda.synchronize()
+
+    rows = []
+    for done, ref in _eval500_checkpoints(step, g, 2 * K):
+        e = sw.engines[0]
+        hist = e.hist.reshape(19, 19).cpu().numpy()
+        rows.append(dict(frames=done, delta=(_miou(hist) - ref["miou"]).tolist(),
+                         moved=float(np.abs(hist - ref["hist"]).sum() / 2 / ref["hist"].sum()),
+                         norm_err=float(np.abs(e.run_proto.norm(dim=1).cpu().numpy() - ref["run_norm"]).max() / ref["run_norm"].max()),
+                         flags_equal=bool(np.array_equal(e.run_flag.cpu().numpy(), ref["rflag"]))))
+        print(rows[-1], flush=True)
+    last = rows[-1]
+    assert last["frames"] == 500 and all(r["flags_equal"] for r in rows)
+    assert np.abs(np.array(last["delta"])).max() <= 0.1, last                 # the north star's bar, single stream, 500 frames
+    assert all(np.abs(np.array(r["delta"])).max() <= 0.2 for r in rows[1:]), rows     # from 100 frames on
+    assert last["moved"] <= 0.02 and max(r["norm_err"] for r in rows) <= 0.02, rows
+
+
+def test_eval_length_stream_500_frames_exact_mode(synth_params_np):
+    """The fp32-exact mode on the same 500-frame stream (25 frames in flight): mIoU within 0.01 of the reference at EVERY
+    50-frame checkpoint, prototype norms to fp32 rounding, flags identical."""
+    from diga_amd.verify import ExactEngine, ExactWeights
+    g = load_golden("net_eval500.npz")
+    K = 25
+    eng = ExactEngine(ExactWeights(synth_params_np, torch.device("cuda:0"), nplanes=3), K, 512, 1024, stream=True)
+
+    def step(frames):
+        x = torch.from_numpy(np.concatenate([a for a, _ in frames])).cuda()
+        y = torch.from_numpy(np.concatenate([b for _, b in frames])).cuda()
+        eng.forward_and_adapt(x, y, CFG)
+        eng.tail(y)
+        torch.cuda.synchronize()
+
+    rows = []
+    for done, ref in _eval500_checkpoints(step, g, K):
+        hist = eng.hist.reshape(19, 19).cpu().numpy()
+        rows.append(dict(frames=done, delta=float(np.abs(_miou(hist) - ref["miou"]).max()),
+                         moved=float(np.abs(hist - ref["hist"]).sum() / 2 / ref["hist"].sum()),
+                         norm_err=float(np.abs(eng.run_proto.norm(dim=1).cpu().numpy() - ref["run_norm"]).max() / ref["run_norm"].max()),
+                         flags_equal=bool(np.array_equal(eng.run_flag.cpu().numpy(), ref["rflag"]))))
+        print(rows[-1], flush=True)
+    assert rows[-1]["frames"] == 500 and all(r["flags_equal"] for r in rows)
+    assert max(r["delta"] for r in rows) <= 0.01, rows
+    assert max(r["norm_err"] for r in rows) <= 1e-4 and max(r["moved"] for r in rows) <= 1e-3, rows
+    ref_final = g["ev_run_final"]
+    assert float(np.abs(eng.run_proto.cpu().numpy() - ref_final).max() / np.abs(ref_final).max()) <= 1e-4
