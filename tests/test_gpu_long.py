@@ -153,11 +153,12 @@ def test_eval_length_stream_500_frames_bf16_path(weights):
 
 
 def test_eval_length_stream_500_frames_exact_mode(synth_params_np):
-    """The fp32-exact mode on the same 500-frame stream (25 frames in flight): mIoU within 0.01 of the reference at EVERY
-    50-frame checkpoint, prototype norms to fp32 rounding, flags identical."""
+    """The fp32-exact mode on the same 500-frame stream (10 frames in flight: three operand planes of 25 frames would exceed the
+    conv kernel's 2 GiB tensor range): mIoU within 0.01 of the reference at EVERY 50-frame checkpoint, prototype norms to fp32
+    rounding, flags identical."""
     from diga_amd.verify import ExactEngine, ExactWeights
     g = load_golden("net_eval500.npz")
-    K = 25
+    K = 10
     eng = ExactEngine(ExactWeights(synth_params_np, torch.device("cuda:0"), nplanes=3), K, 512, 1024, stream=True)
 
     def step(frames):
