@@ -47,9 +47,12 @@ __host__ __device__ inline size_t xb_ticket_off(const XgDev& d) { return xb_epoc
 __host__ __device__ inline size_t xg_error_off(const XgDev& d) { return xb_ticket_off(d) + (size_t)XB_MAX_X * 4; }
 
 // bounded wait until *flag has reached sequence number e (system-scope acquire loads; ~1 us per poll); false = timed out
-__device__ __forceinline__ bool xg_wait_flag(const unsigned* flag, unsigned e, long long timeout_ticks) {
+// `err` = this rank's sticky error word: once a wait has expired the communicator is dead, and every later wait gives up at once
+// (a dead peer costs ONE time-out, not one per exchange of every following step)
+__device__ __forceinline__ bool xg_wait_flag(const unsigned* flag, unsigned e, long long timeout_ticks, const unsigned* err) {
   const long long t0 = wall_clock64();
   while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return false;
     __builtin_amdgcn_s_sleep(8);
     if (wall_clock64() - t0 > timeout_ticks) return false;
   }
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void xgmi_allreduce_kernel(const XgDev d, unsi
     __hip_atomic_store(f, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // 2. wait until every rank's contribution to this block has landed in MY buffer (bounded)
     const unsigned* mine = reinterpret_cast<const unsigned*>(me + xg_flags_off(d)) + (size_t)tid * XG_MAX_BLOCKS + b;
-    if (!xg_wait_flag(mine, e, d.timeout_ticks)) s_fail = 1;
+    if (!xg_wait_flag(mine, e, d.timeout_ticks, reinterpret_cast<const unsigned*>(me + xg_error_off(d)))) s_fail = 1;
   }
   __syncthreads();
   if (s_fail) {
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64 * FIN_PH) void bn_exchange_finalize_kernel(const
     unsigned* f = reinterpret_cast<unsigned*>(d.peer[tid] + xb_flags_off(d)) + (size_t)d.rank * XB_MAX_X + x;
     __hip_atomic_store(f, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned* mine = reinterpret_cast<const unsigned*>(me + xb_flags_off(d)) + (size_t)tid * XB_MAX_X + x;
-    if (!xg_wait_flag(mine, e, d.timeout_ticks)) s_fail = 1;
+    if (!xg_wait_flag(mine, e, d.timeout_ticks, reinterpret_cast<const unsigned*>(me + xg_error_off(d)))) s_fail = 1;
   }
   __syncthreads();
   if (ph < nsets && c < C) {          // thread = (set ph, channel lane)
