@@ -42,7 +42,7 @@ print("# rocprofv3 --pmc over tests/bench_conv.py --batch 15 (15 frames in fligh
 print("# pass 1: SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT")
 print("# pass 2: TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE")
 print("# us / TFLOP/s: event timings printed by bench_conv.py DURING pass 1, i.e. under the profiler (about half the un-profiled speed;")
-print("#   un-profiled per-launch times are in r2_kernel_roofline.md / the bench JSON) -- never compare them with un-profiled timings.")
+print("#   un-profiled per-launch times are in rN_kernel_roofline.md / the bench JSON) -- never compare them with un-profiled timings.")
 print("# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): SIMD-cycles the matrix pipe was busy (= MFMAs x 32,")
 print("#   independent of the tile) over all SIMD-cycles of the launch, both under the profiler's clocks.")
 print("# wait_any / wait_inst / active: share of wave-cycles parked (s_waitcnt, barrier) / stalled at issue (MFMA pipe, dependencies) / issuing.")

@@ -4,7 +4,7 @@
                                  (2 x FETCH_SIZE + WRITE_SIZE) x 1024  (MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE tallies the
                                  128-byte requests of 16-B/lane streams at 64 B -> x2; WRITE_SIZE is exact for 16-B/lane stores;
                                  Infinity-Cache hits are counted, so this is fabric-side traffic, an upper bound of true HBM bytes).
-    python profiles/summarize_r2.py gpurun_out/prof_r2 15 "<provenance text>" """
+    python profiles/summarize_r2.py gpurun_out/prof_r2 15 "<provenance text>" [prefix = r2]      (round 3: gpurun_out/prof_r3 ... r3)"""
 import csv
 import json
 import os
@@ -12,10 +12,11 @@ import shutil
 import sys
 
 src, fif, prov = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+pre = sys.argv[4] if len(sys.argv) > 4 else "r2"
 here = os.path.dirname(os.path.abspath(__file__))
-shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(here, "r2_bench_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(here, f"{pre}_bench_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "trace2", "t_kernel_stats.csv")):
-    shutil.copy(os.path.join(src, "trace2", "t_kernel_stats.csv"), os.path.join(here, "r2_bench_2windows_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "trace2", "t_kernel_stats.csv"), os.path.join(here, f"{pre}_bench_2windows_kernel_stats.csv"))
 
 
 def amode(name):
@@ -49,7 +50,7 @@ out[f"frames_in_flight_{fif}"] = {
     "kernel": "the plain-input igemm launches of one pass (bench.py's `roofline` kernel)",
     "fused_residual_in": {"hbm_bytes_per_step": int((2 * ff + wf) * 1024), "fetch_size_kb_raw": ff, "write_size_kb": wf, "launches": nff},
     "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 over the launches of the last eager pass (fabric-side bytes, Infinity-Cache hits included)",
-    "mode": f"one window of {fif} frames, eager launches, two separate --pmc passes (profiles/collect_r2.sh)", "collected": prov,
+    "mode": f"one window of {fif} frames, eager launches, two separate --pmc passes (profiles/collect_{pre}.sh)", "collected": prov,
 }
 json.dump(out, open(p, "w"), indent=1)
 print(json.dumps(out[f"frames_in_flight_{fif}"]))
