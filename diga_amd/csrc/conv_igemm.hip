@@ -1039,6 +1039,233 @@ int launch_ws(const diga_conv_desc* d, const ConvKParams& p, int epi, int bn, hi
   return DIGA_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A-stationary 1x1 convolution with the DAM apply of its INPUT fused (tile id 93): conv3 of a bottleneck taking conv2's RAW
+// output, A = bf16(relu(fma(raw2, scale, shift))) formed ONCE per element in registers -- act2 is never written and read back
+// (VERDICT r2 item 7).  The fused-input forms above repeat the transform for every N tile that re-reads an element (4-8x
+// on a conv3: measured loss); here a wave keeps one statistics unit (32 rows x K) of transformed A in registers and the
+// WEIGHTS stream past it: 64-column slices through a 3-deep LDS-DMA ring shared by the block's 8 waves, one raw barrier per
+// slice.  The two wave groups of a block run half a phase apart -- waves 0-3: MFMAs of slice q, then its epilogue; waves
+// 4-7: the epilogue of slice q - 1, then the MFMAs of slice q -- so that on every SIMD one wave's statistics / staging / stores
+// run beside the other's MFMAs although the block moves in lockstep.  K order (32-channel MFMA steps, ascending), statistics tree,
+// transform arithmetic and rounding are those of diga_bn_apply + the tiled kernel: output and slab are bit-identical.
+// vmcnt: loads, stores and LDS-DMA count together in issue order (MI355X_MICROARCH.md); a wave issues the pieces of slice q + 2
+// FIRST in interval q, so at the top of interval q + 1 "all but the PCS youngest operations" covers slice q + 1 whatever number of
+// stores the interval issued (never fewer operations behind slice q + 1 than the PCS pieces of slice q + 2; vmcnt(0) at the tail).
+template <int KC>
+__global__ __launch_bounds__(512) void conv1x1_as_kernel(const ConvKParams p, int units_total, int ngroups) {
+  constexpr int BN = 64, NTW = BN / 16, KS = KC / 32, NSTG = 3;
+  constexpr int ROWB = KC * 2, STAGE = BN * ROWB, PCS = STAGE / 8192;
+  constexpr int SW_LD = BN + 8, SW_BYTES = 32 * SW_LD * 2 + 2 * BN * 4;
+  constexpr int LPR = BN / 8, RPS = 64 / LPR, NST = 32 / RPS, SQ = BN / 4;
+  static_assert(PCS >= 1 && STAGE % 8192 == 0, "a stage is a whole number of 8-wave LDS-DMA rounds");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool late = wave >= 4;                        // the wave group that runs its epilogue one interval behind
+  const int l15 = lane & 15, fq = lane >> 4;
+  const int NS = p.Cout / BN;                         // weight slices
+  const int nit = (ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // unit groups of this block
+  const int Q = nit * NS;                             // intervals
+  auto bswz = [](int row) { return KC == 64 ? (row >> 1) & 7 : row & 15; };
+  const unsigned short* const wgt = reinterpret_cast<const unsigned short*>(p.wgt);
+  const unsigned short* const in = reinterpret_cast<const unsigned short*>(p.in);
+  unsigned short* const out = reinterpret_cast<unsigned short*>(p.out);
+  // this lane's source offset inside a slice, per piece: row / slot of the lane-linear LDS image (swizzle on the source side)
+  int woff[PCS];
+#pragma unroll
+  for (int i = 0; i < PCS; ++i) {
+    const int off = (wave + 8 * i) * 1024 + lane * 16;
+    const int row = off / ROWB, slot = (off % ROWB) >> 4;
+    woff[i] = row * KC + ((slot ^ bswz(row)) << 3);
+  }
+  auto issue_slice = [&](int sl, int buf) {
+    const unsigned short* src = wgt + (size_t)sl * BN * KC;
+#pragma unroll
+    for (int i = 0; i < PCS; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(src + woff[i]), (lds_ptr)(smem + buf * STAGE + (wave + 8 * i) * 1024), 16, 0, 0);
+  };
+  unsigned short* const sW = reinterpret_cast<unsigned short*>(smem + NSTG * STAGE + wave * SW_BYTES);
+  float* const sS = reinterpret_cast<float*>(smem + NSTG * STAGE + wave * SW_BYTES + 32 * SW_LD * 2);
+  const int b_swz = bswz(l15);
+
+  u32x4 fa[KS][2];
+  f32x4 acc[2][NTW];
+  auto load_unit = [&](int u) {                        // raw conv2 output of unit u: M tile a, K step k: channels 32k + 8fq .. + 7
+    const int n_img = u / p.units_per_sample, ubase = (u - n_img * p.units_per_sample) * 32;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int row = min(ubase + a * 16 + l15, p.hw - 1);         // rows beyond the sample: any valid address, never used
+      const unsigned short* rp = in + ((size_t)n_img * p.hw + row) * KC + fq * 8;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) fa[k][a] = *reinterpret_cast<const u32x4*>(rp + k * 32);
+    }
+  };
+  auto transform_unit = [&](int u) {                   // bn_apply_kernel<0>'s arithmetic and its single rounding
+    const int n_img = u / p.units_per_sample;
+    const float* sp = p.a_scale + (size_t)n_img * p.a_affine_stride + fq * 8;
+    const float* hp = p.a_shift + (size_t)n_img * p.a_affine_stride + fq * 8;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + k * 32), s1 = *reinterpret_cast<const f32x4*>(sp + k * 32 + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(hp + k * 32), h1 = *reinterpret_cast<const f32x4*>(hp + k * 32 + 4);
+      const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+      const float sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        float v[8];
+        unpack_bf16x8(fa[k][a], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+        fa[k][a] = pack_bf16x8(v);
+      }
+    }
+  };
+  auto mfma_slice = [&](int buf) {
+    const unsigned char* const bB = smem + buf * STAGE + l15 * ROWB;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int coff = ((4 * k + fq) ^ b_swz) << 4;
+      bf16x8 fb[NTW];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(bB + n * 16 * ROWB + coff);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, fa[k][a]);
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, fb[n], acc[a][n], 0, 0, 0);
+      }
+    }
+  };
+  // statistics + staged stores of unit u, columns [n0, n0 + 64): the epilogue of conv1x1_ws_kernel
+  auto epilogue = [&](int u, int n0) {
+    const int n_img = u / p.units_per_sample, ubase = (u - n_img * p.units_per_sample) * 32;
+    const bool full = ubase + 32 <= p.hw;
+    float ksh[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) ksh[n] = p.shift[n0 + n * 16 + l15];
+    auto unit_stats = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
+      unsigned va = 15u, vb = 15u;
+      if constexpr (!FULL) {
+        const int la = p.hw - (ubase + 4 * fq), lb = la - 16;
+        va = la >= 4 ? 15u : la <= 0 ? 0u : (1u << la) - 1u;
+        vb = lb >= 4 ? 15u : lb <= 0 ? 0u : (1u << lb) - 1u;
+      }
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        const f32x2 ga = stat_group<FULL>(acc[0][n][0], acc[0][n][1], acc[0][n][2], acc[0][n][3], ksh[n], va);
+        const f32x2 gb = stat_group<FULL>(acc[1][n][0], acc[1][n][1], acc[1][n][2], acc[1][n][3], ksh[n], vb);
+        sS[(lane >> 5) * BN + n * 16 + l15] = xor_add16(stat_fold32(ga + gb));
+      }
+    };
+    if (full)
+      unit_stats(std::true_type{});
+    else
+      unit_stats(std::false_type{});
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+          const unsigned pk = pack_bf16x2(acc[a][n][i], acc[a][n][i + 1]);
+          sW[(a * 16 + 4 * fq + i) * SW_LD + n * 16 + l15] = (unsigned short)pk;
+          sW[(a * 16 + 4 * fq + i + 1) * SW_LD + n * 16 + l15] = (unsigned short)(pk >> 16);
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    u32x4 ov[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) ov[i] = *reinterpret_cast<const u32x4*>(sW + (i * RPS + lane / LPR) * SW_LD + (lane % LPR) * 8);
+    if (lane < 2 * SQ) {
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(sS + lane * 4);
+      *reinterpret_cast<f32x4*>(&p.slab[((size_t)u * 2 + lane / SQ) * p.Cout + n0 + (lane % SQ) * 4]) = sv;
+    }
+    unsigned short* const orp = out + ((size_t)n_img * p.hw + ubase + lane / LPR) * p.Cout + n0 + (lane % LPR) * 8;
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+      if (full || ubase + i * RPS + lane / LPR < p.hw) __builtin_nontemporal_store(ov[i], reinterpret_cast<u32x4*>(orp + (size_t)i * RPS * p.Cout));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // prologue: slices 0 and 1 on their way
+  issue_slice(0, 0);
+  if (Q > 1) issue_slice(1 % NS, 1);
+  int buf = 0, sl = 0, grp = blockIdx.x;               // ring buffer / slice / unit group of interval q
+  int u = grp * 8 + wave;
+  int pu = 0, pn0 = 0;                                 // (unit, first column) whose accumulators a late wave still holds
+  bool pending = false;
+  for (int q = 0; q < Q; ++q) {
+    if (q + 1 < Q) wait_vmcnt<PCS>(); else wait_vmcnt<0>();        // this wave's pieces of slice q have landed
+    __builtin_amdgcn_s_barrier();                                  // ... everyone's; and everyone is done reading slice q - 1
+    if (q + 2 < Q) issue_slice((sl + 2) % NS, (buf + 2) % NSTG);   // refills the buffer slice q - 1 was read from
+    __builtin_amdgcn_sched_barrier(0);
+    const bool live = u < units_total;
+    if (!late) {
+      if (sl == 0 && live) {
+        load_unit(u);
+        transform_unit(u);
+      }
+      if (live) {
+        mfma_slice(buf);
+        epilogue(u, sl * BN);
+      }
+    } else {
+      if (sl == 0 && live) load_unit(u);               // in flight under the previous slice's epilogue
+      if (pending) epilogue(pu, pn0);
+      if (sl == 0 && live) transform_unit(u);
+      pending = live;
+      if (live) {
+        mfma_slice(buf);
+        pu = u, pn0 = sl * BN;
+      }
+    }
+    buf = buf + 1 == NSTG ? 0 : buf + 1;
+    if (++sl == NS) {
+      sl = 0;
+      grp += gridDim.x;
+      u = grp * 8 + wave;
+    }
+  }
+  if (late && pending) epilogue(pu, pn0);
+}
+
+int launch_as(const diga_conv_desc* d, const ConvKParams& p, int epi, int amode, hipStream_t st) {
+  DIGA_CHECK_ARG(amode == 1, "diga_conv_igemm_bf16_fused_in: tile 93 (A-stationary) takes the plain fused input (no residual); it has no unfused form");
+  DIGA_CHECK_ARG(d->ntaps == 1 && d->stride == 1 && d->dy[0] == 0 && d->dx[0] == 0 && d->H == d->Ho && d->W == d->Wo,
+                 "diga_conv_igemm_bf16_fused_in: tile 93 (A-stationary) is for 1x1 stride-1 convolutions");
+  DIGA_CHECK_ARG((d->Cin == 64 || d->Cin == 128 || d->Cin == 256) && d->Cout % 64 == 0 && d->cout_pad == d->Cout,
+                 "diga_conv_igemm_bf16_fused_in: tile 93 needs Cin in {64, 128, 256} and Cout %% 64 == 0 (got %d -> %d)", d->Cin, d->Cout);
+  DIGA_CHECK_ARG(epi == EPI_BF16_STATS && p.nterms == 1 && d->splitk == 1 && p.fin_ticket == nullptr,
+                 "diga_conv_igemm_bf16_fused_in: tile 93 has the trunk epilogue only (bf16 output + statistics)");
+  const int units_total = d->B * p.units_per_sample, ngroups = cdiv(units_total, 8);
+  const int blocks = ngroups < 256 ? ngroups : 256;          // persistent: one block per CU walks the unit groups
+  const int smem = 3 * 64 * d->Cin * 2 + 8 * (32 * (64 + 8) * 2 + 2 * 64 * 4);
+#define DIGA_AS_LAUNCH(KC)                                                                                              \
+  {                                                                                                                     \
+    static std::once_flag once;                                                                                         \
+    std::call_once(once, [&] {                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_as_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                3 * 64 * KC * 2 + 8 * (32 * (64 + 8) * 2 + 2 * 64 * 4));                                \
+    });                                                                                                                 \
+    hipLaunchKernelGGL(conv1x1_as_kernel<KC>, dim3(blocks), dim3(512), smem, st, p, units_total, ngroups);              \
+  }
+  if (d->Cin == 64) DIGA_AS_LAUNCH(64)
+  else if (d->Cin == 128) DIGA_AS_LAUNCH(128)
+  else DIGA_AS_LAUNCH(256)
+#undef DIGA_AS_LAUNCH
+  return DIGA_OK;
+}
+
 struct TileCfg {
   int id, BM, BN, S, BK = 64;
   bool ilv = false;
@@ -1065,7 +1292,8 @@ const TileCfg kTiles[] = {{1, 128, 128, 4}, {11, 128, 128, 3}, {21, 128, 128, 2}
                           // ids 76 / 77: the shapes of 66 / 67 without interleaved issue -- the fused-input kernels only
                           {76, 256, 128, 2, 32, false}, {77, 128, 256, 2, 32, false},
                           // id 91: conv1x1_ws_kernel (weights-stationary 1x1, Cin <= 256); BM = its 32-row units; id 92: Cin = 512, 64-column slices
-                          {91, 32, 128, 1, 64, false}, {92, 32, 64, 1, 64, false}};
+                          // id 93: conv1x1_as_kernel (A-stationary 1x1 with the fused DAM apply of its input; fused-input entry point only)
+                          {91, 32, 128, 1, 64, false}, {92, 32, 64, 1, 64, false}, {93, 32, 64, 3, 64, false}};
 
 const TileCfg* find_tile(int id) {
   for (const auto& t : kTiles)
@@ -1223,6 +1451,11 @@ int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out
   }
   hipStream_t st = (hipStream_t)stream;
   int e = DIGA_OK;
+  if (fi.amode && t->id == 93) {
+    if (int e93 = launch_as(d, p, epi, fi.amode, st)) return e93;
+    DIGA_CHECK_LAUNCH("diga_conv_igemm_bf16_fused_in");
+    return DIGA_OK;
+  }
   if (fi.amode) {
     switch (t->id) {
       case 21: e = launch_fused_in<128, 128, 2, 2, 64>(p, fi.amode, st); break;

@@ -494,7 +494,11 @@ def test_conv_with_fused_dam_finalize_is_bit_identical(B, H, W, Cin, Cout, k3, d
     # the residual form with two K steps of operand registers in flight (M tiles of 64 / 128 rows, 1x1): ragged samples, two N
     # tiles (only the first writes the block input back), per-sample affines
     (3, 65, 129, 1024, 256, False, 1, True, 3, 27), (2, 33, 41, 512, 512, False, 1, True, 2, 27), (2, 29, 37, 256, 256, False, 1, True, 0, 24),
-    (5, 65, 129, 2048, 512, False, 1, True, 5, 27)])
+    (5, 65, 129, 2048, 512, False, 1, True, 5, 27),
+    # tile 93: the A-stationary conv3 (transform once per element, weights streamed past the resident unit): ragged last units,
+    # fewer units than waves, several unit groups per block (more than 256 groups), per-sample affines
+    (1, 33, 65, 64, 256, False, 1, False, 0, 93), (3, 13, 21, 128, 512, False, 1, False, 3, 93), (2, 65, 129, 256, 1024, False, 1, False, 2, 93),
+    (2, 7, 5, 256, 64, False, 1, False, 0, 93), (5, 65, 129, 256, 1024, False, 1, False, 5, 93), (3, 129, 257, 64, 256, False, 1, False, 3, 93)])
 def test_conv_with_fused_input_apply_is_bit_identical(B, H, W, Cin, Cout, k3, dil, res, per_sample, tile):
     """diga_conv_igemm_bf16_fused_in (DAM apply + ReLU [+ residual] on the operand path) == diga_bn_apply followed by
     diga_conv_igemm_bf16: raw output and statistics slab bit for bit; in the residual form the activation written on the side
