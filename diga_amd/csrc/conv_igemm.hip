@@ -1046,10 +1046,13 @@ int launch_ws(const diga_conv_desc* d, const ConvKParams& p, int epi, int bn, hi
 // (VERDICT r2 item 7).  The fused-input forms above repeat the transform for every N tile that re-reads an element (4-8x
 // on a conv3: measured loss); here a wave keeps one statistics unit (32 rows x K) of transformed A in registers and the
 // WEIGHTS stream past it: 64-column slices through a 3-deep LDS-DMA ring shared by the block's 8 waves, one raw barrier per
-// slice.  The two wave groups of a block run half a phase apart -- waves 0-3: MFMAs of slice q, then its epilogue; waves
-// 4-7: the epilogue of slice q - 1, then the MFMAs of slice q -- so that on every SIMD one wave's statistics / staging / stores
-// run beside the other's MFMAs although the block moves in lockstep.  K order (32-channel MFMA steps, ascending), statistics tree,
-// transform arithmetic and rounding are those of diga_bn_apply + the tiled kernel: output and slab are bit-identical.
+// slice.  K order (32-channel MFMA steps, ascending), statistics tree, transform arithmetic and rounding are those of diga_bn_apply +
+// the tiled kernel: output and slab are bit-identical (tests/test_gpu_kernels.py).
+// MEASURED (round 3, layer3's conv3 at 15 frames): 135 us against 22 + 95 us for diga_bn_apply + the weights-stationary kernel, so
+// the engine does NOT use it.  Phase clock: an interval's per-wave chain is 1 450 cycles of MFMA phase (64 MFMAs = 1 024 issue cycles)
+// + 2 300 of epilogue for its 32 accumulator registers + ~600 of barrier / DMA issue, and the block's lockstep lets nothing overlap
+// it; the weights-stationary kernel spends 8 450 cycles on twice the columns with its waves drifting freely.  Two units per wave would
+// halve the fixed share but need 128 + 64 + 32 registers at K = 256.
 // vmcnt: loads, stores and LDS-DMA count together in issue order (MI355X_MICROARCH.md); a wave issues the pieces of slice q + 2
 // FIRST in interval q, so at the top of interval q + 1 "all but the PCS youngest operations" covers slice q + 1 whatever number of
 // stores the interval issued (never fewer operations behind slice q + 1 than the PCS pieces of slice q + 2; vmcnt(0) at the tail).
@@ -1065,7 +1068,12 @@ __global__ __launch_bounds__(512) void conv1x1_as_kernel(const ConvKParams p, in
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool late = wave >= 4;                        // the wave group that runs its epilogue one interval behind
+  // stagger: waves 4-7 run their epilogue one interval behind (epilogue of slice q - 1, then the MFMAs of slice q) so that on every
+  // SIMD one wave's statistics / staging / stores run beside the other's MFMAs.  Built, bit-identical, and SLOWER (148 vs 135 us on
+  // layer3's conv3 at 15 frames: the late waves' epilogue, contended by their partners' MFMA phase, takes 3 800 cycles instead of
+  // 2 300 and the early waves sit 2 800 cycles at the barrier -- phase clock, profiles/experiments/as_conv3_r3.log): off
+  constexpr bool kStagger = false;
+  const bool late = kStagger && wave >= 4;
   const int l15 = lane & 15, fq = lane >> 4;
   const int NS = p.Cout / BN;                         // weight slices
   const int nit = (ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // unit groups of this block
@@ -1090,12 +1098,24 @@ __global__ __launch_bounds__(512) void conv1x1_as_kernel(const ConvKParams p, in
   };
   unsigned short* const sW = reinterpret_cast<unsigned short*>(smem + NSTG * STAGE + wave * SW_BYTES);
   float* const sS = reinterpret_cast<float*>(smem + NSTG * STAGE + wave * SW_BYTES + 32 * SW_LD * 2);
+  // the statistics shift of every output channel, once, in LDS: a register load of it inside the slice loop would make the
+  // compiler drain the vector-memory counter -- and with it the weight slices in flight -- in every epilogue
+  float* const sK = reinterpret_cast<float*>(smem + NSTG * STAGE + 8 * SW_BYTES);
+  for (int c = tid; c < p.Cout; c += 512) sK[c] = p.shift[c];
   const int b_swz = bswz(l15);
 
   u32x4 fa[KS][2];
   f32x4 acc[2][NTW];
+  // this wave's copy of its unit's DAM affine (scale [KC] | shift [KC]): two 16-byte loads per lane together with the unit's rows,
+  // then LDS reads per K step (loading the 8 + 8 values of every K step from memory took one round trip per step)
+  float* const sAf = reinterpret_cast<float*>(smem + NSTG * STAGE + 8 * SW_BYTES + 4 * KC * 4 + wave * 2 * KC * 4);
+  f32x4 afs = {0.f, 0.f, 0.f, 0.f}, afh = {0.f, 0.f, 0.f, 0.f};
   auto load_unit = [&](int u) {                        // raw conv2 output of unit u: M tile a, K step k: channels 32k + 8fq .. + 7
     const int n_img = u / p.units_per_sample, ubase = (u - n_img * p.units_per_sample) * 32;
+    if (lane * 4 < KC) {
+      afs = *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)n_img * p.a_affine_stride + lane * 4);
+      afh = *reinterpret_cast<const f32x4*>(p.a_shift + (size_t)n_img * p.a_affine_stride + lane * 4);
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const int row = min(ubase + a * 16 + l15, p.hw - 1);         // rows beyond the sample: any valid address, never used
@@ -1104,14 +1124,18 @@ __global__ __launch_bounds__(512) void conv1x1_as_kernel(const ConvKParams p, in
       for (int k = 0; k < KS; ++k) fa[k][a] = *reinterpret_cast<const u32x4*>(rp + k * 32);
     }
   };
-  auto transform_unit = [&](int u) {                   // bn_apply_kernel<0>'s arithmetic and its single rounding
-    const int n_img = u / p.units_per_sample;
-    const float* sp = p.a_scale + (size_t)n_img * p.a_affine_stride + fq * 8;
-    const float* hp = p.a_shift + (size_t)n_img * p.a_affine_stride + fq * 8;
+  auto transform_unit = [&]() {                        // bn_apply_kernel<0>'s arithmetic and its single rounding
+    if (lane * 4 < KC) {
+      *reinterpret_cast<f32x4*>(sAf + lane * 4) = afs;
+      *reinterpret_cast<f32x4*>(sAf + KC + lane * 4) = afh;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + k * 32), s1 = *reinterpret_cast<const f32x4*>(sp + k * 32 + 4);
-      const f32x4 h0 = *reinterpret_cast<const f32x4*>(hp + k * 32), h1 = *reinterpret_cast<const f32x4*>(hp + k * 32 + 4);
+      const float* sp = sAf + k * 32 + fq * 8;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(sp + KC), h1 = *reinterpret_cast<const f32x4*>(sp + KC + 4);
       const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
       const float sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
 #pragma unroll
@@ -1123,6 +1147,8 @@ __global__ __launch_bounds__(512) void conv1x1_as_kernel(const ConvKParams p, in
         fa[k][a] = pack_bf16x8(v);
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the affine copy has been read: the next unit may overwrite it)
+    __builtin_amdgcn_wave_barrier();
   };
   auto mfma_slice = [&](int buf) {
     const unsigned char* const bB = smem + buf * STAGE + l15 * ROWB;
@@ -1150,7 +1176,7 @@ __global__ __launch_bounds__(512) void conv1x1_as_kernel(const ConvKParams p, in
     const bool full = ubase + 32 <= p.hw;
     float ksh[NTW];
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) ksh[n] = p.shift[n0 + n * 16 + l15];
+    for (int n = 0; n < NTW; ++n) ksh[n] = sK[n0 + n * 16 + l15];
     auto unit_stats = [&](auto full_c) {
       constexpr bool FULL = decltype(full_c)::value;
       unsigned va = 15u, vb = 15u;
@@ -1182,53 +1208,93 @@ __global__ __launch_bounds__(512) void conv1x1_as_kernel(const ConvKParams p, in
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    // EXACTLY NST + 1 stores per epilogue (the interval waits below count them): rows beyond the sample re-store the sample's last
+    // row with that row's own values -- the same bytes to the same address, harmless -- instead of being skipped
+    const int rlast = p.hw - 1 - ubase;               // last row of the unit inside the sample (>= 31 for a full unit)
     u32x4 ov[NST];
+    int orow[NST];
 #pragma unroll
-    for (int i = 0; i < NST; ++i) ov[i] = *reinterpret_cast<const u32x4*>(sW + (i * RPS + lane / LPR) * SW_LD + (lane % LPR) * 8);
-    if (lane < 2 * SQ) {
-      const f32x4 sv = *reinterpret_cast<const f32x4*>(sS + lane * 4);
-      *reinterpret_cast<f32x4*>(&p.slab[((size_t)u * 2 + lane / SQ) * p.Cout + n0 + (lane % SQ) * 4]) = sv;
+    for (int i = 0; i < NST; ++i) {
+      orow[i] = min(i * RPS + lane / LPR, rlast);
+      ov[i] = *reinterpret_cast<const u32x4*>(sW + orow[i] * SW_LD + (lane % LPR) * 8);
     }
-    unsigned short* const orp = out + ((size_t)n_img * p.hw + ubase + lane / LPR) * p.Cout + n0 + (lane % LPR) * 8;
+    {
+      const int sl_ = lane < 2 * SQ ? lane : lane - 2 * SQ;      // (lanes 32-63 repeat lanes 0-31: one unconditional store)
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(sS + sl_ * 4);
+      *reinterpret_cast<f32x4*>(&p.slab[((size_t)u * 2 + sl_ / SQ) * p.Cout + n0 + (sl_ % SQ) * 4]) = sv;
+    }
+    unsigned short* const orp = out + ((size_t)n_img * p.hw + ubase) * p.Cout + n0 + (lane % LPR) * 8;
 #pragma unroll
-    for (int i = 0; i < NST; ++i)
-      if (full || ubase + i * RPS + lane / LPR < p.hw) __builtin_nontemporal_store(ov[i], reinterpret_cast<u32x4*>(orp + (size_t)i * RPS * p.Cout));
+    for (int i = 0; i < NST; ++i) __builtin_nontemporal_store(ov[i], reinterpret_cast<u32x4*>(orp + (size_t)orow[i] * p.Cout));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   };
+  constexpr int EST = NST + 1;                         // stores of one epilogue
 
-  // prologue: slices 0 and 1 on their way
+  // prologue: slices 0 and 1 on their way; the shift table is complete before anyone's first epilogue (the loop's first barrier)
   issue_slice(0, 0);
   if (Q > 1) issue_slice(1 % NS, 1);
   int buf = 0, sl = 0, grp = blockIdx.x;               // ring buffer / slice / unit group of interval q
   int u = grp * 8 + wave;
   int pu = 0, pn0 = 0;                                 // (unit, first column) whose accumulators a late wave still holds
   bool pending = false;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's sK writes)
+  // Operations this wave issued AFTER the pieces of the slice it is about to wait for, oldest first: the stores of the interval
+  // those pieces were issued in (st1: 0 or EST), the pieces of the following slice (PCS, none at the tail), the stores of the interval
+  // just finished (st0).  "All but that many youngest operations are done" is exactly "the slice has landed" -- a wait that also
+  // covered the stores would put a store's round trip into every interval (measured: 4.5 us per interval instead of ~2).
+  int st0 = 0, st1 = 0;
+#ifdef DIGA_TILE_CLOCK
+  unsigned long long ck[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct = clock64();
+#define AS_CLK(i)                        \
+  {                                      \
+    const unsigned long long t_ = clock64(); \
+    ck[i] += t_ - ct;                    \
+    ct = t_;                             \
+  }
+#else
+#define AS_CLK(i) \
+  do {            \
+  } while (0)
+#endif
   for (int q = 0; q < Q; ++q) {
-    if (q + 1 < Q) wait_vmcnt<PCS>(); else wait_vmcnt<0>();        // this wave's pieces of slice q have landed
+    {
+      const int younger = st1 + st0 + (q > 0 && q + 1 < Q ? PCS : 0);       // (q = 0: both prologue slices are still in front)
+      if (q == 0) { if (Q > 1) wait_vmcnt<PCS>(); else wait_vmcnt<0>(); }
+      else if (younger == 2 * EST + PCS) wait_vmcnt<2 * EST + PCS>();
+      else if (younger == EST + PCS) wait_vmcnt<EST + PCS>();
+      else if (younger == PCS) wait_vmcnt<PCS>();
+      else if (younger == 2 * EST) wait_vmcnt<2 * EST>();
+      else if (younger == EST) wait_vmcnt<EST>();
+      else wait_vmcnt<0>();
+    }
     __builtin_amdgcn_s_barrier();                                  // ... everyone's; and everyone is done reading slice q - 1
+    AS_CLK(0);
     if (q + 2 < Q) issue_slice((sl + 2) % NS, (buf + 2) % NSTG);   // refills the buffer slice q - 1 was read from
     __builtin_amdgcn_sched_barrier(0);
     const bool live = u < units_total;
-    if (!late) {
-      if (sl == 0 && live) {
-        load_unit(u);
-        transform_unit(u);
-      }
-      if (live) {
-        mfma_slice(buf);
-        epilogue(u, sl * BN);
-      }
-    } else {
-      if (sl == 0 && live) load_unit(u);               // in flight under the previous slice's epilogue
-      if (pending) epilogue(pu, pn0);
-      if (sl == 0 && live) transform_unit(u);
+    st1 = st0;
+    st0 = (late ? pending : live) ? EST : 0;            // the epilogue this interval runs
+    // one body for both wave groups: [late: epilogue of the previous interval] [MFMAs of this slice] [early: its epilogue]
+    AS_CLK(1);
+    if (sl == 0 && live) load_unit(u);                 // (late waves: in flight under the epilogue below)
+    AS_CLK(2);
+    if (late && pending) epilogue(pu, pn0);
+    AS_CLK(3);
+    if (sl == 0 && live) transform_unit();
+    AS_CLK(4);
+    if (live) mfma_slice(buf);
+#ifdef DIGA_TILE_CLOCK
+    asm volatile("s_nop 0" : "+v"(acc[0][0]), "+v"(acc[1][NTW - 1]));   // (the stamp below follows the MFMAs' results)
+#endif
+    AS_CLK(5);
+    if (late) {
       pending = live;
-      if (live) {
-        mfma_slice(buf);
-        pu = u, pn0 = sl * BN;
-      }
+      pu = u, pn0 = sl * BN;
+    } else if (live) {
+      epilogue(u, sl * BN);
     }
+    AS_CLK(6);
     buf = buf + 1 == NSTG ? 0 : buf + 1;
     if (++sl == NS) {
       sl = 0;
@@ -1237,25 +1303,34 @@ __global__ __launch_bounds__(512) void conv1x1_as_kernel(const ConvKParams p, in
     }
   }
   if (late && pending) epilogue(pu, pn0);
+#ifdef DIGA_TILE_CLOCK
+  if (lane == 0 && blockIdx.x < 2048) {
+    unsigned long long* g = g_tile_clock + ((size_t)blockIdx.x * 8 + wave) * 8;
+    for (int i = 0; i < 7; ++i) g[i] = ck[i];
+    g[7] = Q;
+  }
+#endif
+#undef AS_CLK
 }
 
 int launch_as(const diga_conv_desc* d, const ConvKParams& p, int epi, int amode, hipStream_t st) {
   DIGA_CHECK_ARG(amode == 1, "diga_conv_igemm_bf16_fused_in: tile 93 (A-stationary) takes the plain fused input (no residual); it has no unfused form");
   DIGA_CHECK_ARG(d->ntaps == 1 && d->stride == 1 && d->dy[0] == 0 && d->dx[0] == 0 && d->H == d->Ho && d->W == d->Wo,
                  "diga_conv_igemm_bf16_fused_in: tile 93 (A-stationary) is for 1x1 stride-1 convolutions");
-  DIGA_CHECK_ARG((d->Cin == 64 || d->Cin == 128 || d->Cin == 256) && d->Cout % 64 == 0 && d->cout_pad == d->Cout,
-                 "diga_conv_igemm_bf16_fused_in: tile 93 needs Cin in {64, 128, 256} and Cout %% 64 == 0 (got %d -> %d)", d->Cin, d->Cout);
+  DIGA_CHECK_ARG((d->Cin == 64 || d->Cin == 128 || d->Cin == 256) && d->Cout % 64 == 0 && d->Cout <= 4 * d->Cin && d->cout_pad == d->Cout,
+                 "diga_conv_igemm_bf16_fused_in: tile 93 needs Cin in {64, 128, 256}, Cout %% 64 == 0 and Cout <= 4 Cin (got %d -> %d)", d->Cin, d->Cout);
   DIGA_CHECK_ARG(epi == EPI_BF16_STATS && p.nterms == 1 && d->splitk == 1 && p.fin_ticket == nullptr,
                  "diga_conv_igemm_bf16_fused_in: tile 93 has the trunk epilogue only (bf16 output + statistics)");
   const int units_total = d->B * p.units_per_sample, ngroups = cdiv(units_total, 8);
   const int blocks = ngroups < 256 ? ngroups : 256;          // persistent: one block per CU walks the unit groups
-  const int smem = 3 * 64 * d->Cin * 2 + 8 * (32 * (64 + 8) * 2 + 2 * 64 * 4);
+  const int smem = 3 * 64 * d->Cin * 2 + 8 * (32 * (64 + 8) * 2 + 2 * 64 * 4) + 4 * d->Cin * 4 + 8 * 2 * d->Cin * 4;
+  DIGA_CHECK_ARG(smem <= 160 * 1024, "diga_conv_igemm_bf16_fused_in: tile 93: Cout %d needs %d bytes of LDS", d->Cout, smem);
 #define DIGA_AS_LAUNCH(KC)                                                                                              \
   {                                                                                                                     \
     static std::once_flag once;                                                                                         \
     std::call_once(once, [&] {                                                                                          \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_as_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                3 * 64 * KC * 2 + 8 * (32 * (64 + 8) * 2 + 2 * 64 * 4));                                \
+                                3 * 64 * KC * 2 + 8 * (32 * (64 + 8) * 2 + 2 * 64 * 4) + 4 * KC * 4 + 8 * 2 * KC * 4);  \
     });                                                                                                                 \
     hipLaunchKernelGGL(conv1x1_as_kernel<KC>, dim3(blocks), dim3(512), smem, st, p, units_total, ngroups);              \
   }
