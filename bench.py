@@ -182,11 +182,16 @@ def miou_vs_reference(weights, dev, fif, nwin, autotune, seed=0):
     from diga_amd import synth
     from diga_amd.pipeline import StreamWindows
     from diga_amd.ttda_module import SegmentationMetric
-    path = os.path.join(ROOT, "tests", "golden", "net_stream.npz" if seed == 0 else "net_streams_ms.npz")
+    path = os.path.join(ROOT, "tests", "golden", "net_eval500.npz" if seed == "eval500" else "net_stream.npz" if seed == 0 else "net_streams_ms.npz")
     if not os.path.exists(path):
         return None
     with np.load(path, allow_pickle=False) as z:
-        if seed == 0:
+        if seed == "eval500":              # ONE evaluation-length stream (500 frames = GTA5 -> Cityscapes val, README.md:241-243), frame seed 0
+            nframes = int(z["ev_frames"])
+            ref = [float(v) for v in z[f"ev_{nframes}_miou"]]
+            ref_hist = z[f"ev_{nframes}_hist"]
+            seed = 0
+        elif seed == 0:
             ref = [float(v) for v in z["st_miou"]]
             nframes = int(z["st_frames"])
             ref_hist = z[f"st_{nframes - 1}_hist"]
@@ -224,7 +229,7 @@ def miou_vs_reference(weights, dev, fif, nwin, autotune, seed=0):
             "delta": [round(a - b, 4) for a, b in zip(got, ref)], "bar": 0.1,
             "confusion_entries_differing": int((hist.numpy() != ref_hist).sum()),
             "pixels_moved": int(np.abs(hist.numpy() - ref_hist).sum() // 2),
-            "source": "tests/golden/net_stream.npz: the reference's forward_and_adapt + Upsample + SegmentationMetric on the same frames (fp32, CPU)"}
+            "source": f"tests/golden/{os.path.basename(path)}: the reference's forward_and_adapt + Upsample + SegmentationMetric on the same frames (fp32, CPU)"}
 
 
 def spawn_ranks(args, argv):
@@ -410,7 +415,8 @@ def main():
     ap.add_argument("--no-calibration", action="store_true", help="skip the library-GEMM / device-copy peak check")
     ap.add_argument("--no-latency-mode", action="store_true", help="skip the extra one-frame-per-step measurement")
     ap.add_argument("--no-exact-mode", action="store_true", help="skip the throughput / logit-error leg of the fp32-exact verification mode")
-    ap.add_argument("--no-miou", action="store_true", help="skip the mIoU-vs-reference leg (8 frames through the measured configuration)")
+    ap.add_argument("--no-miou", action="store_true", help="skip the mIoU-vs-reference leg (five 30-frame streams + one 500-frame stream through the measured configuration)")
+    ap.add_argument("--no-eval-stream", action="store_true", help="skip the 500-frame stream of the mIoU-vs-reference leg (about 20 s)")
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="N=1 only: run the N>1 code path (eager launches, one window, per-layer reduce_slab + RCCL all-reduce + "
                          "finalize_sums, prototype exchange) through a single-rank nccl group: what the sharded step costs before any "
@@ -600,15 +606,22 @@ def main():
         # delta is one draw of the bf16 rounding noise, tests/test_gpu_net.py::test_stream_miou_vs_reference_five_streams)
         streams = [miou_vs_reference(weights, dev, fif, nwin, not args.no_autotune, seed=sd) for sd in range(5)]
         streams = [r for r in streams if r is not None]
+        # ... and ONE stream of evaluation length (500 frames) through the same configuration: there the bar holds on the single
+        # stream, the storage noise of the individual frames averages out (tests/test_gpu_long.py)
+        eval_stream = None if args.no_eval_stream else miou_vs_reference(weights, dev, fif, nwin, not args.no_autotune, seed="eval500")
+        if eval_stream is not None:
+            eval_stream = {k: eval_stream[k] for k in ("frames", "miou19_16_13", "reference", "delta", "bar", "pixels_moved", "source")}
+            eval_stream["within_bar"] = [bool(abs(d) <= 0.1) for d in eval_stream["delta"]]
         if streams:
             mean_delta = [round(float(np.mean([r["delta"][i] for r in streams])), 4) for i in range(3)]
             res["miou_vs_reference"] = dict(
                 streams[0], streams=[{"frame_seed": r["frame_seed"], "delta": r["delta"],
                                       "within_bar": [bool(abs(d) <= 0.1) for d in r["delta"]]} for r in streams],
                 mean_delta=mean_delta, mean_within_bar=[bool(abs(d) <= 0.1) for d in mean_delta],
+                eval_length_stream=eval_stream,
                 gate=("the +-0.1 bar is asserted on the MEAN over the streams (tests/test_gpu_net.py::test_stream_miou_vs_reference_five_streams); "
                       "a single 30-frame stream's delta is one draw of the bf16 storage noise (DESIGN.md 1, tests/golden/bf16_floor.json) and is "
-                      "reported per stream with its own pass/fail; the fp32-exact mode holds +-0.01 on every stream (tests/test_gpu_exact.py)"))
+                      "reported per stream with its own pass/fail; on the 500-frame stream (`eval_length_stream`) the bar holds on the single stream; the fp32-exact mode holds +-0.01 on every stream (tests/test_gpu_exact.py)"))
     if rank == 0 and world == 1 and not args.no_exact_mode:
         # parity-grade throughput: the fp32-exact mode on the same stream (fp32x3 = fp32-grade products, fp32x2 = "bf16x3")
         torch.cuda.empty_cache()
