@@ -100,8 +100,8 @@ class OneShotComm:
         call("diga_xgmi_set_timeout_ms", self._comm, int(ms))
 
     def self_test(self, rounds: int = 3) -> bool:
-        """A few all-reduces with known answers (fp64, fp32, int32) through the mapped buffers: True when every result is the
-        exact rank-order sum and no wait expired.  Run by every rank at set-up, before the transport is trusted with statistics."""
+        """A few all-reduces with known answers (fp64, fp32, int32) through the mapped buffers, then the fused BN exchange against
+        the three-launch form: True when every result is the exact rank-order sum / the same bits and no wait expired.  Run by every rank at set-up, before the transport is trusted with statistics."""
         ok = True
         n = 4 * 2048
         base = torch.arange(1, n + 1, dtype=torch.float64, device="cuda")
@@ -111,10 +111,44 @@ class OneShotComm:
                 t = ((base + r) * (self.rank + 1)).to(dt)
                 self.all_reduce(t)
                 ok = ok and bool(torch.equal(t, ((base + r) * tri).to(dt)))
+        ok = ok and self._self_test_bn()
         try:
             self.check()
         except _lib.DigaError:
             return False
+        return ok
+
+    def _self_test_bn(self) -> bool:
+        """The fused exchange against the three-launch form it replaces (diga_bn_reduce_slab + all_reduce + diga_bn_finalize_sums,
+        the all_reduce having just been checked): scale / shift must be the SAME BITS, in both batch rules (a stream of global
+        batches: per-sample sets; one global batch: groups A / B), twice in a row (both parities of the slots)."""
+        p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+        st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)      # noqa: E731
+        C_, ups, ns = 256, 5, 3
+        g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+        rm, rv = torch.linspace(-1, 1, C_).cuda(), torch.linspace(0.5, 2, C_).cuda()
+        w, b = torch.linspace(0.8, 1.2, C_).cuda(), torch.linspace(-0.1, 0.1, C_).cuda()
+        rows = 32.0 * ups
+        ok = True
+        for rep in range(2):
+            slab = torch.randn(ns * ups, 2, C_, generator=g)
+            slab[:, 1] = slab[:, 1].abs() * 32 + 40.0           # sum of squares >= (sum)^2 / rows, loosely
+            slab = slab.cuda()
+            for per_sample, a_samples, nsets in ((1, 1 if self.rank == 0 else 0, ns), (0, ns if self.rank == 0 else 0, 1)):
+                if per_sample:
+                    n_a, n_b = rows, rows * (self.world - 1)
+                else:
+                    n_a, n_b = rows * ns, rows * ns * (self.world - 1)
+                if n_b == 0:
+                    n_a, n_b = n_a / 2, n_a / 2                 # world 1: any positive counts do
+                fused = [torch.full((nsets * C_,), float("nan"), device="cuda") for _ in range(2)]
+                self.bn_exchange_finalize(slab, ups, ns, a_samples, per_sample, C_, n_a, n_b, rm, rv, w, b, 0.8, 1e-5, *fused)
+                sums = torch.zeros(nsets * 4 * C_, dtype=torch.float64, device="cuda")
+                call("diga_bn_reduce_slab", p(slab), ups, ns, a_samples, per_sample, C_, p(sums), st())
+                self.all_reduce(sums)
+                plain = [torch.full((nsets * C_,), float("nan"), device="cuda") for _ in range(2)]
+                call("diga_bn_finalize_sums", p(sums), nsets, C_, n_a, n_b, p(rm), p(rv), p(w), p(b), 0.8, 1e-5, p(plain[0]), p(plain[1]), st())
+                ok = ok and all(bool(torch.equal(f, q)) and bool(torch.isfinite(f).all()) for f, q in zip(fused, plain))
         return ok
 
     def close(self):
