@@ -812,14 +812,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
 // Tile id 92 = the same kernel with 64-column slices for K = 512 (layer4's conv3, layer3's downsample): the slice is again 64 KiB
 // of LDS, a wave's A fragments are 128 registers and its MFMA work per unit (128) equals that of a K = 256, 128-column unit, while
 // the epilogue -- statistics, staging and stores are what a unit's time is made of -- covers half as many accumulators.
-template <int KC, int BN>
-__global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, int units_total, int units_per_group) {
-  constexpr int NTW = BN / 16, KS = KC / 32;
-  constexpr int LPR = BN / 8, RPS = 64 / LPR, NST = 32 / RPS;   // output stores: lanes per row, rows per store instruction, stores per unit
-  constexpr int SQ = BN / 4;                                    // statistics read-back: lanes per row of the unit's [2][BN] words
+// NP > 1 (tile id 94): a unit's BN columns are taken in NP passes of BN / NP columns over the SAME A registers -- half the accumulators
+// and weight fragments per pass, so that NW = 12 waves (three per SIMD instead of two, <= 168 registers) share the resident slice.
+template <int KC, int BN, int NP = 1, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void conv1x1_ws_kernel(const ConvKParams p, int units_total, int units_per_group) {
+  constexpr int BNP = BN / NP;                                  // columns per pass
+  constexpr int NTW = BN / 16, NTP = BNP / 16, KS = KC / 32;
+  constexpr int LPR = BNP / 8, RPS = 64 / LPR, NST = 32 / RPS;  // output stores: lanes per row, rows per store instruction, stores per pass
+  constexpr int SQ = BNP / 4;                                   // statistics read-back: lanes per row of the pass's [2][BNP] words
   constexpr int ROWB = KC * 2, B_BYTES = BN * ROWB;
-  constexpr int SW_LD = BN + 8;                                // a wave's staging tile: 32 rows, 16 bytes of padding per row,
-  constexpr int SW_BYTES = 32 * SW_LD * 2 + 2 * BN * 4;        // + the unit's 2 x 128 statistics words (one 16-byte store per lane)
+  constexpr int SW_LD = BNP + 8;                               // a wave's staging tile: 32 rows, 16 bytes of padding per row,
+  constexpr int SW_BYTES = 32 * SW_LD * 2 + 2 * BNP * 4;       // + the pass's 2 x BNP statistics words (one 16-byte store per lane)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef DIGA_TILE_CLOCK
   const unsigned long long wk0 = wall_clock64();
@@ -843,12 +846,11 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
     const unsigned short* wgt = reinterpret_cast<const unsigned short*>(p.wgt);
-#pragma unroll
-    for (int i = 0; i < B_BYTES / 8192; ++i) {
-      const int off = (wave + 8 * i) * 1024 + lane * 16;
+    for (int pc = wave; pc < B_BYTES / 1024; pc += NW) {          // 1 KiB pieces, wave-uniform trip count
+      const int off = pc * 1024 + lane * 16;
       const int row = off / ROWB, slot = (off % ROWB) >> 4;
       __builtin_amdgcn_global_load_lds((gbl_ptr)(wgt + (size_t)(n0 + row) * KC + ((slot ^ bswz(row)) << 3)),
-                                       (lds_ptr)(smem + (wave + 8 * i) * 1024), 16, 0, 0);
+                                       (lds_ptr)(smem + pc * 1024), 16, 0, 0);
     }
   }
   float ksh[NTW];
@@ -883,6 +885,11 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
 #pragma unroll
       for (int a = 0; a < 2; ++a) fa[k][a] = *reinterpret_cast<const u32x4*>(rp[a] + k * 32);
   }
+#ifdef DIGA_WS_STAGGER
+  // waves w and w + NW / 2 share a SIMD (a workgroup's waves go round the SIMDs): started together they stay in phase -- both in the
+  // K loop, then both in the epilogue -- and nothing overlaps; the second half starts half a unit late
+  if (wave >= NW / 2) __builtin_amdgcn_s_sleep(DIGA_WS_STAGGER);
+#endif
 #ifdef DIGA_TILE_CLOCK
   unsigned long long wc[4] = {0, 0, 0, 0}, wt0 = clock64(), wr0 = wall_clock64();
 #define DIGA_WCLK(i, t0) wc[i] += clock64() - (t0)
@@ -891,35 +898,50 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
   do {                  \
   } while (0)
 #endif
-  for (; u < u_end; u += 8) {
+  for (; u < u_end; u += NW) {
+    const int un = u + NW < u_end ? u + NW : u;       // the last unit re-reads itself: no branch in the body
+    const unsigned short* rp[2];
+    unit_rows(un, rp);
+    const int n_img = u / p.units_per_sample, ubase = (u - n_img * p.units_per_sample) * 32;
+    const bool full = ubase + 32 <= p.hw;
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
 #ifdef DIGA_TILE_CLOCK
     const unsigned long long c0 = clock64();
 #endif
-    const int un = u + 8 < u_end ? u + 8 : u;         // the last unit re-reads itself: no branch in the body
-    const unsigned short* rp[2];
-    unit_rows(un, rp);
-    f32x4 acc[2][NTW];
+    f32x4 acc[2][NTP];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int n = 0; n < NTW; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int n = 0; n < NTP; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     // (plain loads: the compiler counts them.  Issuing and counting them by hand -- vmcnt(2 (KS - 1) + stores per unit), so
     // that a K step never waits for the previous unit's stores -- was built and measured: no gain, 105 vs 107 us)
+#ifdef DIGA_EXP_WS_NOB   /* experiment only (profiles/experiments/ws_ablate): the weight fragments are read from LDS once per unit */
+    bf16x8 fb[NTP];
+#endif
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       const int coff = ((4 * k + fq) ^ b_swz) << 4;
-      bf16x8 fb[NTW];
+#ifdef DIGA_EXP_WS_NOB
+      if (k == 0)
+#else
+      bf16x8 fb[NTP];
+#endif
 #pragma unroll
-      for (int n = 0; n < NTW; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(bB + n * 16 * ROWB + coff);
+      for (int n = 0; n < NTP; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(bB + (ps * NTP + n) * 16 * ROWB + coff);
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const bf16x8 av = __builtin_bit_cast(bf16x8, fa[k][a]);
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) acc[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, fb[n], acc[a][n], 0, 0, 0);
+        for (int n = 0; n < NTP; ++n) acc[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, fb[n], acc[a][n], 0, 0, 0);
       }
       // this K step's registers are free: the next unit's fragments go into them while the remaining steps run
+#ifndef DIGA_EXP_WS_NOA  /* experiment only: without it the first unit's A fragments are re-used for every unit */
+      if (ps == NP - 1) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a) fa[k][a] = *reinterpret_cast<const u32x4*>(rp[a] + k * 32);
+        for (int a = 0; a < 2; ++a) fa[k][a] = *reinterpret_cast<const u32x4*>(rp[a] + k * 32);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     DIGA_WCLK(0, c0);
@@ -927,8 +949,6 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
     const unsigned long long c1 = clock64();
 #endif
     // ---- the unit's statistics (the tree of the tiled kernel) and its 32 x 128 outputs
-    const int n_img = u / p.units_per_sample, ubase = (u - n_img * p.units_per_sample) * 32;
-    const bool full = ubase + 32 <= p.hw;
     auto unit_stats = [&](auto full_c) {
       constexpr bool FULL = decltype(full_c)::value;
       unsigned va = 15u, vb = 15u;                     // rows of this lane's two groups inside the sample (ragged last unit)
@@ -938,22 +958,41 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
         vb = lb >= 4 ? 15u : lb <= 0 ? 0u : (1u << lb) - 1u;
       }
 #pragma unroll
-      for (int n = 0; n < NTW; ++n) {
-        const f32x2 ga = stat_group<FULL>(acc[0][n][0], acc[0][n][1], acc[0][n][2], acc[0][n][3], ksh[n], va);
-        const f32x2 gb = stat_group<FULL>(acc[1][n][0], acc[1][n][1], acc[1][n][2], acc[1][n][3], ksh[n], vb);
+      for (int n = 0; n < NTP; ++n) {
+        const f32x2 ga = stat_group<FULL>(acc[0][n][0], acc[0][n][1], acc[0][n][2], acc[0][n][3], ksh[ps * NTP + n], va);
+        const f32x2 gb = stat_group<FULL>(acc[1][n][0], acc[1][n][1], acc[1][n][2], acc[1][n][3], ksh[ps * NTP + n], vb);
         const float w = xor_add16(stat_fold32(ga + gb));
         // lanes 0-31 hold the unit's sum, lanes 32-63 its sum of squares (lanes fq and fq ^ 1 the same word): collected in
         // LDS and stored below with ONE 16-byte store per lane -- store instructions, not bytes, are what an epilogue pays for
-        sS[(lane >> 5) * BN + n * 16 + l15] = w;
+        sS[(lane >> 5) * BNP + n * 16 + l15] = w;
       }
     };
+#ifdef DIGA_EXP_WS_NOEPI   /* experiments only (profiles/experiments/ws_ablate): parts of the epilogue left out, results wrong */
+    {
+      float t = 0.f;
+#pragma unroll
+      for (int n = 0; n < NTP; ++n) t += acc[0][n][0] + acc[1][n][3];
+      if (t == 123.456f) sS[lane] = t;      // keeps the MFMAs alive
+      continue;
+    }
+#endif
+#ifndef DIGA_EXP_WS_NOSTAT
     if (full)
       unit_stats(std::true_type{});
     else
       unit_stats(std::false_type{});
+#endif
     DIGA_WCLK(3, c1);
+#ifdef DIGA_EXP_WS_NOSTAGE
+    {
+      float t = 0.f;
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) {
+      for (int n = 0; n < NTP; ++n) t += acc[0][n][0] + acc[1][n][3] + acc[0][n][1] + acc[1][n][2];
+      if (t == 123.456f) sW[lane] = (unsigned short)lane;
+    }
+#else
+#pragma unroll
+    for (int n = 0; n < NTP; ++n) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -963,6 +1002,7 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
           sW[(a * 16 + 4 * fq + i + 1) * SW_LD + n * 16 + l15] = (unsigned short)(pk >> 16);
         }
     }
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's staging writes are done (LDS ops of one wave stay in order)
     __builtin_amdgcn_wave_barrier();
     DIGA_WCLK(1, c1);
@@ -975,9 +1015,9 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
     for (int i = 0; i < NST; ++i) ov[i] = *reinterpret_cast<const u32x4*>(sW + (i * RPS + lane / LPR) * SW_LD + (lane % LPR) * 8);
     if (lane < 2 * SQ) {                                                       // row lane / SQ, columns 4 (lane % SQ) .. + 3
       const f32x4 sv = *reinterpret_cast<const f32x4*>(sS + lane * 4);
-      *reinterpret_cast<f32x4*>(&p.slab[((size_t)u * 2 + lane / SQ) * p.Cout + n0 + (lane % SQ) * 4]) = sv;
+      *reinterpret_cast<f32x4*>(&p.slab[((size_t)u * 2 + lane / SQ) * p.Cout + n0 + ps * BNP + (lane % SQ) * 4]) = sv;
     }
-    unsigned short* const orp = out + (orow + lane / LPR) * p.Cout + n0 + (lane % LPR) * 8;
+    unsigned short* const orp = out + (orow + lane / LPR) * p.Cout + n0 + ps * BNP + (lane % LPR) * 8;
     if (full) {
 #pragma unroll
       for (int i = 0; i < NST; ++i) __builtin_nontemporal_store(ov[i], reinterpret_cast<u32x4*>(orp + (size_t)i * RPS * p.Cout));
@@ -989,52 +1029,60 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvKParams p, in
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging tile has been read: the next unit may overwrite it
     __builtin_amdgcn_wave_barrier();
     DIGA_WCLK(2, c2);
+    }  // passes
   }
 #ifdef DIGA_TILE_CLOCK
   if (lane == 0 && blockIdx.x < 2048) {
-    unsigned long long* g = g_tile_clock + ((size_t)blockIdx.x * 8 + wave) * 8;
+    unsigned long long* g = g_tile_clock + ((size_t)blockIdx.x * NW + wave) * 8;
     g[0] = wc[0], g[1] = wc[1], g[2] = wc[2], g[3] = clock64() - wt0, g[4] = wall_clock64() - wr0;
-    g[5] = (u_end - u_begin - wave + 7) / 8;
+    g[5] = (u_end - u_begin - wave + NW - 1) / NW;
     g[6] = wc[3];
     g[7] = wr0 - wk0;
   }
 #endif
 }
 
-int launch_ws(const diga_conv_desc* d, const ConvKParams& p, int epi, int bn, hipStream_t st) {
-  const int id = bn == 128 ? 91 : 92;
+int launch_ws(const diga_conv_desc* d, const ConvKParams& p, int epi, int id, hipStream_t st) {
+  const int bn = id == 92 ? 64 : 128;                      // columns of the resident slice
+  const int np = id == 94 ? 2 : 1, nw = id == 94 ? 12 : 8;   // passes per unit, waves per block
   DIGA_CHECK_ARG(d->ntaps == 1 && d->stride == 1 && d->dy[0] == 0 && d->dx[0] == 0 && d->H == d->Ho && d->W == d->Wo,
                  "diga_conv_igemm_bf16: tile %d (weights-stationary) is for 1x1 stride-1 convolutions", id);
-  if (bn == 128)
+  if (id != 92)
     DIGA_CHECK_ARG((d->Cin == 64 || d->Cin == 128 || d->Cin == 256) && d->Cout % 128 == 0 && d->cout_pad == d->Cout,
-                   "diga_conv_igemm_bf16: tile 91 needs Cin in {64, 128, 256} and Cout %% 128 == 0 (got %d -> %d)", d->Cin, d->Cout);
+                   "diga_conv_igemm_bf16: tile %d needs Cin in {64, 128, 256} and Cout %% 128 == 0 (got %d -> %d)", id, d->Cin, d->Cout);
   else
     DIGA_CHECK_ARG(d->Cin == 512 && d->Cout % 64 == 0 && d->cout_pad == d->Cout,
                    "diga_conv_igemm_bf16: tile 92 needs Cin = 512 and Cout %% 64 == 0 (got %d -> %d)", d->Cin, d->Cout);
   DIGA_CHECK_ARG(epi == EPI_BF16_STATS && p.nterms == 1 && d->splitk == 1 && p.fin_ticket == nullptr,
                  "diga_conv_igemm_bf16: tile %d has the trunk epilogue only (bf16 output + statistics)", id);
   const int units_total = d->B * p.units_per_sample, nslices = d->Cout / bn;
-  // one block per CU (its LDS): as many unit groups as fill the chip once, at least 8 units (one per wave) per group
+  // one block per CU (its LDS): as many unit groups as fill the chip once, at least one unit per wave and group
   int groups = 256 / nslices;
   if (groups < 1) groups = 1;
-  if (groups > cdiv(units_total, 8)) groups = cdiv(units_total, 8);
+  if (groups > cdiv(units_total, nw)) groups = cdiv(units_total, nw);
   const int upg = cdiv(units_total, groups);
   groups = cdiv(units_total, upg);
-  const int smem = bn * d->Cin * 2 + 8 * (32 * (bn + 8) * 2 + 2 * bn * 4);
-  dim3 grid(groups * nslices), block(512);
-#define DIGA_WS_LAUNCH(KC, BN)                                                                                          \
+  const int bnp = bn / np;
+  const int smem = bn * d->Cin * 2 + nw * (32 * (bnp + 8) * 2 + 2 * bnp * 4);
+  dim3 grid(groups * nslices), block(64 * nw);
+#define DIGA_WS_LAUNCH(KC, BN, NP, NW)                                                                                  \
   {                                                                                                                     \
     static std::once_flag once;                                                                                         \
     std::call_once(once, [&] {                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_kernel<KC, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                BN * KC * 2 + 8 * (32 * (BN + 8) * 2 + 2 * BN * 4));                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_kernel<KC, BN, NP, NW>),                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize,                                             \
+                                BN * KC * 2 + NW * (32 * (BN / NP + 8) * 2 + 2 * (BN / NP) * 4));                       \
     });                                                                                                                 \
-    hipLaunchKernelGGL((conv1x1_ws_kernel<KC, BN>), grid, block, smem, st, p, units_total, upg);                        \
+    hipLaunchKernelGGL((conv1x1_ws_kernel<KC, BN, NP, NW>), grid, block, smem, st, p, units_total, upg);                \
   }
-  if (d->Cin == 64) DIGA_WS_LAUNCH(64, 128)
-  else if (d->Cin == 128) DIGA_WS_LAUNCH(128, 128)
-  else if (d->Cin == 256) DIGA_WS_LAUNCH(256, 128)
-  else DIGA_WS_LAUNCH(512, 64)
+  if (id == 94) {
+    if (d->Cin == 64) DIGA_WS_LAUNCH(64, 128, 2, 12)
+    else if (d->Cin == 128) DIGA_WS_LAUNCH(128, 128, 2, 12)
+    else DIGA_WS_LAUNCH(256, 128, 2, 12)
+  } else if (d->Cin == 64) DIGA_WS_LAUNCH(64, 128, 1, 8)
+  else if (d->Cin == 128) DIGA_WS_LAUNCH(128, 128, 1, 8)
+  else if (d->Cin == 256) DIGA_WS_LAUNCH(256, 128, 1, 8)
+  else DIGA_WS_LAUNCH(512, 64, 1, 8)
 #undef DIGA_WS_LAUNCH
   return DIGA_OK;
 }
@@ -1368,7 +1416,8 @@ const TileCfg kTiles[] = {{1, 128, 128, 4}, {11, 128, 128, 3}, {21, 128, 128, 2}
                           {76, 256, 128, 2, 32, false}, {77, 128, 256, 2, 32, false},
                           // id 91: conv1x1_ws_kernel (weights-stationary 1x1, Cin <= 256); BM = its 32-row units; id 92: Cin = 512, 64-column slices
                           // id 93: conv1x1_as_kernel (A-stationary 1x1 with the fused DAM apply of its input; fused-input entry point only)
-                          {91, 32, 128, 1, 64, false}, {92, 32, 64, 1, 64, false}, {93, 32, 64, 3, 64, false}};
+                          {91, 32, 128, 1, 64, false}, {92, 32, 64, 1, 64, false}, {93, 32, 64, 3, 64, false},
+                          {94, 32, 128, 1, 64, false}};
 
 const TileCfg* find_tile(int id) {
   for (const auto& t : kTiles)
@@ -1550,8 +1599,8 @@ int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out
     DIGA_CHECK_LAUNCH("diga_conv_igemm_bf16_fused_in");
     return DIGA_OK;
   }
-  if (t->id == 91 || t->id == 92) {
-    if (int e91 = launch_ws(d, p, epi, t->BN, st)) return e91;
+  if (t->id == 91 || t->id == 92 || t->id == 94) {
+    if (int e91 = launch_ws(d, p, epi, t->id, st)) return e91;
     DIGA_CHECK_LAUNCH("diga_conv_igemm_bf16");
     return DIGA_OK;
   }
