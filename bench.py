@@ -372,6 +372,26 @@ def run_config(args, world, rank, dev, group, weights, fif, steps, warmup, nwin=
         healthy, why = False, str(ex)
     if one_shot_on and rank == world - 1 and os.environ.get("DIGA_BENCH_INJECT_TRANSPORT_FAILURE"):
         healthy, why = False, "injected by DIGA_BENCH_INJECT_TRANSPORT_FAILURE (test of the fallback)"
+    run_config.exchange_verified = None
+    if world > 1 and sharded:
+        # end-to-end check of the exchanges, whatever the transport: global-batch statistics mean that EVERY rank holds the same
+        # bits of scale / shift for all 104 BN layers and of the running prototypes after the last step -- a raced or torn
+        # exchange would show as ranks that disagree (signature = two wrapping int64 sums over the raw words; MIN == MAX over ranks)
+        import torch.distributed as dist
+        sig = []
+        for e in engines:
+            for t in (e.scale, e.shift, e.run_proto):
+                v = t.contiguous().view(torch.int32).to(torch.int64).reshape(-1)
+                sig += [v.sum(), (v * torch.arange(1, v.numel() + 1, device=v.device)).sum()]
+        sig = torch.stack(sig)
+        if dist.get_backend() != "nccl":
+            sig = sig.cpu()
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        run_config.exchange_verified = bool(torch.equal(lo, hi))
+        if not run_config.exchange_verified and healthy:
+            healthy, why = False, "the ranks disagree on the bits of scale / shift / prototypes after the last step"
     if world > 1 and one_shot_on:
         import torch.distributed as dist
         flag = torch.tensor([1 if healthy else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -502,7 +522,10 @@ def main():
                    "resolution": f"{W}x{H}", "feature_grid": f"{eng.wd}x{eng.h}", "weights": "seeded synthetic init (diga_amd/synth.py)",
                    "launch": "hipGraph replay" if use_graph else "eager", "backend": backend if world > 1 else ("nccl, single-rank rehearsal of the exchange path" if args.rehearse_exchange else None),
                    "exchange_transport": run_config.transport, "exchange_launches_per_step": run_config.exchange_launches or None,
-                   "exchange_transport_fallback": fallback, "conv_tiles": "autotuned per shape" if eng.autotune else "fixed rule",
+                   "exchange_transport_fallback": fallback,
+                   "exchange_verified": ("every rank holds the same bits of scale / shift (104 BN layers) and running prototypes after the last step"
+                                         if run_config.exchange_verified else run_config.exchange_verified),
+                   "conv_tiles": "autotuned per shape" if eng.autotune else "fixed rule",
                    "includes": "net + SAM + fusion + upsample/argmax/confusion tail",
                    "first_eager_step_s": first_pass_s,
                    "frames_per_step": fif * nwin, "windows": nwin, "conv_gflop_per_frame": round(eng.conv_flops / fif / 1e9, 3)},

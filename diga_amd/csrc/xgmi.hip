@@ -5,12 +5,20 @@
 // slots in fixed rank order: one kernel launch per exchange, deterministic, identical bits on every rank, capturable in a
 // HIP graph (the sequence number lives in device memory).  No counterpart in the reference (it has no distributed code).
 //
-// Memory model: the buffer is ordinary device memory shared through hipIpc.  Data and flags are written with system-scope
-// stores / atomics and a system-scope fence in between, and read with system-scope atomic loads, so that neither the writer's
-// nor the reader's L2 can hold them back or serve stale lines.  Waiting is a BOUNDED spin: a peer that never arrives makes the
+// Memory model: the buffer is UNCACHED (fine-grained) device memory shared through hipIpc; every access to it -- payload, flags,
+// tickets, epochs -- is a system-scope atomic load / store / add (sc0 sc1 on the instruction: it goes past both L2s by itself).
+// Ordering between them ("payload before flag", "flag before payload") is then a matter of THIS wave's own operations having
+// completed, i.e. `s_waitcnt vmcnt(0)` between the two (xg_order): the stores have been acknowledged by the memory system before
+// the flag store issues; a load's data has returned before the loads that depend on its value issue.  The C++ fences that say the
+// same thing (release / acquire at system scope) additionally write back and invalidate the WHOLE L2 of the XCD
+// (buffer_wbl2 / buffer_inv sc0 sc1) -- for lines that are never cached -- and the L2 is where the convolutions of the other window
+// keep their operands: with fences in all 212 exchange launches of a step the sharded step ran 6 % slower than the unsharded one
+// (766 vs 814 frames/s, one rank), so they are used only when the buffer could NOT be allocated uncached (`XgDev.fences`; or
+// DIGA_XGMI_FENCES=1 in the environment, for A/B runs).  Waiting is a BOUNDED spin: a peer that never arrives makes the
 // call fail (error word, DIGA_ELAUNCH from diga_xgmi_check) instead of hanging the GPU.
 #include "common.h"
 #include "dam_affine.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -31,7 +39,16 @@ struct XgDev {                                // passed to the kernel by value
   int world, rank;
   long long max_elems;                        // 8-byte elements per slot
   long long timeout_ticks;                    // bound of every wait, in wall_clock64() ticks
+  int fences;                                 // 1: system-scope C++ fences around flags (cached buffer / DIGA_XGMI_FENCES=1), 0: xg_order
 };
+
+// "everything this wave has issued so far is done" -- the ordering point between payload and flag accesses (see the header)
+__device__ __forceinline__ void xg_order(int fences) {
+  if (fences)
+    __threadfence_system();
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 // buffer layout (bytes): [2 parities][world][max_elems] x 8 | flags [world][XG_MAX_BLOCKS] u32 | epoch [XG_MAX_BLOCKS] u32 |
 //   region B: [2 parities][world][XB_SLOT_ELEMS] x 8 | flagsB [world][XB_MAX_X] u32 | epochB [XB_MAX_X] u32 | ticketB [XB_MAX_X] u32 | error u32
@@ -49,13 +66,14 @@ __host__ __device__ inline size_t xg_error_off(const XgDev& d) { return xb_ticke
 // bounded wait until *flag has reached sequence number e (system-scope acquire loads; ~1 us per poll); false = timed out
 // `err` = this rank's sticky error word: once a wait has expired the communicator is dead, and every later wait gives up at once
 // (a dead peer costs ONE time-out, not one per exchange of every following step)
-__device__ __forceinline__ bool xg_wait_flag(const unsigned* flag, unsigned e, long long timeout_ticks, const unsigned* err) {
+__device__ __forceinline__ bool xg_wait_flag(const unsigned* flag, unsigned e, long long timeout_ticks, const unsigned* err, int fences) {
   const long long t0 = wall_clock64();
-  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return false;
     __builtin_amdgcn_s_sleep(8);
     if (wall_clock64() - t0 > timeout_ticks) return false;
   }
+  xg_order(fences);          // (the value has been compared, so the load is done; with fences: the acquire)
   return true;
 }
 __host__ __device__ inline size_t xg_total_bytes(const XgDev& d) { return (xg_error_off(d) + 4 + 255) / 256 * 256; }
@@ -86,14 +104,14 @@ __global__ __launch_bounds__(256) void xgmi_allreduce_kernel(const XgDev d, unsi
     for (long long i = lo + tid; i < hi; i += 256)
       __hip_atomic_store(dst + i, data[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __threadfence_system();
-  __syncthreads();
+  xg_order(d.fences);        // every thread: its payload stores have been acknowledged ...
+  __syncthreads();           // ... all of the block's, before a flag goes out
   if (tid < d.world) {
     unsigned* f = reinterpret_cast<unsigned*>(d.peer[tid] + xg_flags_off(d)) + (size_t)d.rank * XG_MAX_BLOCKS + b;
-    __hip_atomic_store(f, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(f, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // 2. wait until every rank's contribution to this block has landed in MY buffer (bounded)
     const unsigned* mine = reinterpret_cast<const unsigned*>(me + xg_flags_off(d)) + (size_t)tid * XG_MAX_BLOCKS + b;
-    if (!xg_wait_flag(mine, e, d.timeout_ticks, reinterpret_cast<const unsigned*>(me + xg_error_off(d)))) s_fail = 1;
+    if (!xg_wait_flag(mine, e, d.timeout_ticks, reinterpret_cast<const unsigned*>(me + xg_error_off(d)), d.fences)) s_fail = 1;
   }
   __syncthreads();
   if (s_fail) {
@@ -135,6 +153,7 @@ __global__ __launch_bounds__(256) void xgmi_allreduce_kernel(const XgDev d, unsi
       data[i] = out;
     }
   }
+  xg_order(d.fences);        // the slots have been read: a peer that sees the next flag may overwrite this parity two exchanges on
   __syncthreads();
   if (tid == 0) epoch[b] = e;
 }
@@ -181,17 +200,20 @@ __global__ __launch_bounds__(64 * FIN_PH) void bn_exchange_finalize_kernel(const
 #pragma unroll
       for (int k = 0; k < 4; ++k) __hip_atomic_store(dst + k * 64, Acc<double>::to_bits(s[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
+    xg_order(d.fences);      // wave 0 wrote them all: acknowledged before the ticket is taken
   }
   __syncthreads();
-  if (tid == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM) == (unsigned)(nsets - 1);
+  if (tid == 0) {
+    s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == (unsigned)(nsets - 1);
+    xg_order(d.fences);      // the ticket's value is here: every earlier taker's sums had been acknowledged before its add
+  }
   __syncthreads();
   if (!s_last) return;
   if (tid < d.world) {
     unsigned* f = reinterpret_cast<unsigned*>(d.peer[tid] + xb_flags_off(d)) + (size_t)d.rank * XB_MAX_X + x;
-    __hip_atomic_store(f, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(f, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned* mine = reinterpret_cast<const unsigned*>(me + xb_flags_off(d)) + (size_t)tid * XB_MAX_X + x;
-    if (!xg_wait_flag(mine, e, d.timeout_ticks, reinterpret_cast<const unsigned*>(me + xg_error_off(d)))) s_fail = 1;
+    if (!xg_wait_flag(mine, e, d.timeout_ticks, reinterpret_cast<const unsigned*>(me + xg_error_off(d)), d.fences)) s_fail = 1;
   }
   __syncthreads();
   if (ph < nsets && c < C) {          // thread = (set ph, channel lane)
@@ -212,6 +234,7 @@ __global__ __launch_bounds__(64 * FIN_PH) void bn_exchange_finalize_kernel(const
       dam_affine_from_sums(s, c, n_a, n_b, rmean, rvar, weight, bias, lam, eps, sc, sh);
     }
   }
+  xg_order(d.fences);        // the slots have been read before the epoch moves on
   __syncthreads();
   if (tid == 0) {
     if (s_fail) __hip_atomic_store(reinterpret_cast<unsigned*>(me + xg_error_off(d)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -248,10 +271,13 @@ extern "C" int diga_xgmi_create(int world, int rank, int64_t max_elems, void** c
   // set-up time: the exchange itself never allocates.  Uncached (fine-grained) device memory, as RCCL uses for its own peer
   // buffers: remote writes and local reads do not depend on L2 write-back / invalidation; plain device memory as a fallback.
   hipError_t e = hipExtMallocWithFlags(&buf, xg_total_bytes(c->dev), hipDeviceMallocUncached);
+  const char* env = getenv("DIGA_XGMI_FENCES");
+  c->dev.fences = env && env[0] == '1';
   if (e != hipSuccess) {
     (void)hipGetLastError();
     buf = nullptr;
     e = hipMalloc(&buf, xg_total_bytes(c->dev));
+    c->dev.fences = 1;        // a cached buffer: lines of it may sit in an L2, only the fences' write-back / invalidate reach them
   }
   if (e == hipSuccess) e = hipMemset(buf, 0, xg_total_bytes(c->dev));
   hipIpcMemHandle_t h;

@@ -561,6 +561,7 @@ def test_bench_spawns_its_own_ranks_and_replays_a_graph():
     assert line["n_gpus"] == 2 and line["config"]["launch"] == "hipGraph replay", line["config"]
     assert line["config"]["exchange_launches_per_step"] == 2 * 106, line["config"]
     assert "one-shot" in line["config"]["exchange_transport"] and "rehearsal" in line
+    assert line["config"]["exchange_verified"], line["config"]        # all ranks: the same bits of scale / shift / prototypes
     assert line["value"] > 0
 
 
