@@ -348,6 +348,9 @@ int diga_upsample_argmax_hist_frames(const float* probs, const void* target, int
  * diga_xgmi_allreduce: in-place sum over ranks of `count` values at `data` (device, 8-byte aligned); dtype 0 = fp64,
  *   1 = fp32, 2 = int32 (4-byte types: count even); count*size <= max_elems*8.  Every rank must issue the same sequence of
  *   calls (same counts) on ONE stream per communicator (two streams = two communicators).
+ * Ordering: the buffer is uncached device memory and every access to it is a system-scope atomic, so "payload before flag" /
+ *   "flag before payload" are this wave's own `s_waitcnt vmcnt(0)` between them; no cache-wide write-back / invalidate is issued
+ *   (a buffer that could not be allocated uncached, or DIGA_XGMI_FENCES=1 in the environment: system-scope fences instead).
  * Waits are bounded by wall-clock time (default 30 s, diga_xgmi_set_timeout_ms): when a peer has not arrived by then the launch
  *   ends, POISONS its payload (NaN for fp64 / fp32, INT32_MIN for int32, NaN scale / shift) and raises a sticky error word;
  *   diga_xgmi_check (synchronises the device) turns that word into DIGA_ELAUNCH.  A communicator that has failed is dead.
