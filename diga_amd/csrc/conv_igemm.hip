@@ -91,6 +91,16 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // ---- DAM statistics of one unit (32 consecutive rows of a sample x one channel), summed in ONE fixed tree whatever the
 // tile shape, the MFMA shape or the kernel, so that a unit's bits never depend on who produced it:
 //   4-row group g (rows 4g .. 4g+3), d = x - shift[c]:   S_g = (d0 + d2) + (d1 + d3),   Q_g = fma(d2, d2, d0*d0) + fma(d3, d3, d1*d1)
@@ -1091,6 +1101,245 @@ int launch_ws(const diga_conv_desc* d, const ConvKParams& p, int epi, int id, hi
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Weights-stationary 1x1 convolution, software-pipelined inside the wave (tile id 95).
+//
+// The ablations of tile 91 (profiles/experiments/ws_ablate) say its parts ADD -- a wave's K loop (waits for its LDS / global
+// reads) and its epilogue (a chain of ~400 dependent vector / LDS / store instructions) run one after the other, 8 450 cycles
+// per unit for 2 048 cycles of MFMA, and two waves per SIMD are not enough to cover each other.  Here a wave overlaps them
+// ITSELF: a unit's 128 columns are taken as two halves of 64 (two accumulator sets of 32 registers over the same A registers),
+// and while the MFMAs of one half run, the epilogue of the PREVIOUS half -- statistics and staging of one 16-column tile per K
+// step, then the read-back, then the stores -- is issued between them.  Same K order, same statistics tree, same rounding:
+// bit-identical to tiles 91 / 23 (tests/test_gpu_kernels.py).
+template <int KC, int NW>
+__global__ __launch_bounds__(64 * NW) void conv1x1_wsp_kernel(const ConvKParams p, int units_total, int units_per_group) {
+  constexpr int BN = 128, BNP = 64, NTW = BN / 16, NTP = BNP / 16, KS = KC / 32;
+  constexpr int LPR = BNP / 8, RPS = 64 / LPR, NST = 32 / RPS;   // output stores of one half: lanes per row, rows per store, stores
+  constexpr int SQ = BNP / 4;
+  constexpr int ROWB = KC * 2, B_BYTES = BN * ROWB;
+  constexpr int SW_LD = BNP + 8;
+  constexpr int SW_BYTES = 32 * SW_LD * 2 + 2 * BNP * 4;
+  constexpr int PPS = 8 / KS;                                    // epilogue parts per K step (8 parts: 4 tiles, read-back, stores, -, -)
+  static_assert(KS == 8 || KS == 4 || KS == 2, "K = 256 / 128 / 64");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, fq = lane >> 4;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int nslices = p.Cout / BN;
+  const int grp = bid / nslices, n0 = (bid - grp * nslices) * BN;
+  const int u_begin = grp * units_per_group, u_end = min(u_begin + units_per_group, units_total);
+  auto bswz = [](int row) { return KC == 64 ? (row >> 1) & 7 : row & 15; };
+  {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    const unsigned short* wgt = reinterpret_cast<const unsigned short*>(p.wgt);
+    for (int pc = wave; pc < B_BYTES / 1024; pc += NW) {
+      const int off = pc * 1024 + lane * 16;
+      const int row = off / ROWB, slot = (off % ROWB) >> 4;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(wgt + (size_t)(n0 + row) * KC + ((slot ^ bswz(row)) << 3)),
+                                       (lds_ptr)(smem + pc * 1024), 16, 0, 0);
+    }
+  }
+  float ksh[NTW];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) ksh[n] = p.shift[n0 + n * 16 + l15];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const unsigned short* const in = reinterpret_cast<const unsigned short*>(p.in);
+  unsigned short* const out = reinterpret_cast<unsigned short*>(p.out);
+  unsigned short* const sW = reinterpret_cast<unsigned short*>(smem + B_BYTES + wave * SW_BYTES);
+  float* const sS = reinterpret_cast<float*>(smem + B_BYTES + wave * SW_BYTES + 32 * SW_LD * 2);
+  const unsigned char* const bB = smem + l15 * ROWB;
+  const int b_swz = bswz(l15);
+
+  u32x4 fa[KS][2];
+  auto unit_rows = [&](int u, const unsigned short** rp) {
+    const int n_img = u / p.units_per_sample, ubase = (u - n_img * p.units_per_sample) * 32;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int row = min(ubase + a * 16 + l15, p.hw - 1);
+      rp[a] = in + ((size_t)n_img * p.hw + row) * KC + fq * 8;
+    }
+  };
+  int u = u_begin + wave;
+  if (u < u_end) {
+    const unsigned short* rp[2];
+    unit_rows(u, rp);
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[k][a] = *reinterpret_cast<const u32x4*>(rp[a] + k * 32);
+  }
+
+  // ---- one part of the epilogue of a finished half (its accumulators `ac`, unit uE = (n_img, ubase), half HE): parts 0..3 = the
+  // statistics and the staging writes of 16-column tile `part`; 4 = read-back and stores.  FULL (the unit lies inside its sample)
+  // is a template argument chosen ONCE per half, so that a K step with its epilogue part is one basic block the scheduler can
+  // interleave
+  auto epi_part = [&](auto part_c, auto he_c, auto full_c, f32x4 (&ac)[2][NTP], int uE, int n_img, int ubase) {
+    constexpr int part = decltype(part_c)::value, HE = decltype(he_c)::value;
+    constexpr bool FULL = decltype(full_c)::value;
+    if constexpr (part < NTP) {
+      constexpr int n = part;
+      unsigned va = 15u, vb = 15u;
+      if constexpr (!FULL) {
+        const int la = p.hw - (ubase + 4 * fq), lb = la - 16;
+        va = la >= 4 ? 15u : la <= 0 ? 0u : (1u << la) - 1u;
+        vb = lb >= 4 ? 15u : lb <= 0 ? 0u : (1u << lb) - 1u;
+      }
+      const f32x2 ga = stat_group<FULL>(ac[0][n][0], ac[0][n][1], ac[0][n][2], ac[0][n][3], ksh[HE * NTP + n], va);
+      const f32x2 gb = stat_group<FULL>(ac[1][n][0], ac[1][n][1], ac[1][n][2], ac[1][n][3], ksh[HE * NTP + n], vb);
+      const float w = xor_add16(stat_fold32(ga + gb));
+      sS[(lane >> 5) * BNP + n * 16 + l15] = w;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+          const unsigned pk = pack_bf16x2(ac[a][n][i], ac[a][n][i + 1]);
+          sW[(a * 16 + 4 * fq + i) * SW_LD + n * 16 + l15] = (unsigned short)pk;
+          sW[(a * 16 + 4 * fq + i + 1) * SW_LD + n * 16 + l15] = (unsigned short)(pk >> 16);
+        }
+    } else if constexpr (part == NTP) {
+      // (LDS ops of one wave stay in order: the reads below see this wave's staging writes)
+      u32x4 ov[NST];
+#pragma unroll
+      for (int i = 0; i < NST; ++i) ov[i] = *reinterpret_cast<const u32x4*>(sW + (i * RPS + lane / LPR) * SW_LD + (lane % LPR) * 8);
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(sS + (lane & (2 * SQ - 1)) * 4);
+      const size_t orow = (size_t)n_img * p.hw + ubase;
+      if (lane < 2 * SQ)
+        *reinterpret_cast<f32x4*>(&p.slab[((size_t)uE * 2 + lane / SQ) * p.Cout + n0 + HE * BNP + (lane % SQ) * 4]) = sv;
+      unsigned short* const orp = out + (orow + lane / LPR) * p.Cout + n0 + HE * BNP + (lane % LPR) * 8;
+      if constexpr (FULL) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) __builtin_nontemporal_store(ov[i], reinterpret_cast<u32x4*>(orp + (size_t)i * RPS * p.Cout));
+      } else {
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+          if (ubase + i * RPS + lane / LPR < p.hw) __builtin_nontemporal_store(ov[i], reinterpret_cast<u32x4*>(orp + (size_t)i * RPS * p.Cout));
+      }
+    }
+  };
+
+  // ---- one half: the MFMAs of half H of the current unit into `am`; EPI: with the epilogue of the pending half (`ae`, unit uE,
+  // half 1 - H) issued between the K steps.  No branch inside: one basic block per half, the
+  // scheduler interleaves the epilogue's vector instructions with the MFMAs and hoists the next step's LDS reads.
+  auto half = [&](auto h_c, auto epi_c, auto full_c, f32x4 (&am)[2][NTP], f32x4 (&ae)[2][NTP], int uE, const unsigned short* const* rp) {
+    constexpr int H = decltype(h_c)::value;
+    constexpr bool EPI = decltype(epi_c)::value;
+    int n_img = 0, ubase = 0;
+    if constexpr (EPI) {
+      n_img = uE / p.units_per_sample;
+      ubase = (uE - n_img * p.units_per_sample) * 32;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int n = 0; n < NTP; ++n) am[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_for<KS>([&](auto k_c) {
+      constexpr int k = decltype(k_c)::value;
+      const int coff = ((4 * k + fq) ^ b_swz) << 4;
+      bf16x8 fb[NTP];
+#pragma unroll
+      for (int n = 0; n < NTP; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(bB + (H * NTP + n) * 16 * ROWB + coff);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, fa[k][a]);
+#pragma unroll
+        for (int n = 0; n < NTP; ++n) am[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, fb[n], am[a][n], 0, 0, 0);
+      }
+      if constexpr (H == 1) {      // the unit's last use of this K step's A registers: the next unit's fragments go into them
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa[k][a] = *reinterpret_cast<const u32x4*>(rp[a] + k * 32);
+      }
+      if constexpr (EPI)
+        static_for<PPS>([&](auto q_c) {
+          epi_part(std::integral_constant<int, k * PPS + decltype(q_c)::value>{}, std::integral_constant<int, 1 - H>{}, full_c, ae, uE, n_img, ubase);
+        });
+      __builtin_amdgcn_sched_barrier(0x100);      // only LDS reads (the next step's weight fragments) may move across K steps
+    });
+  };
+  auto is_full = [&](int uE) {
+    const int n_img = uE / p.units_per_sample, ubase = (uE - n_img * p.units_per_sample) * 32;
+    return ubase + 32 <= p.hw;
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+
+  f32x4 acc0[2][NTP], acc1[2][NTP];
+  bool pend = false;
+  int uprev = u;
+  for (; u < u_end; u += NW) {
+    const int un = u + NW < u_end ? u + NW : u;
+    const unsigned short* rp[2];
+    unit_rows(un, rp);
+    if (!pend)
+      half(C0{}, std::false_type{}, std::true_type{}, acc0, acc1, uprev, rp);
+    else if (is_full(uprev))
+      half(C0{}, std::true_type{}, std::true_type{}, acc0, acc1, uprev, rp);
+    else
+      half(C0{}, std::true_type{}, std::false_type{}, acc0, acc1, uprev, rp);
+    if (is_full(u))
+      half(C1{}, std::true_type{}, std::true_type{}, acc1, acc0, u, rp);
+    else
+      half(C1{}, std::true_type{}, std::false_type{}, acc1, acc0, u, rp);
+    pend = true;
+    uprev = u;
+  }
+  if (pend) {
+    const int n_img = uprev / p.units_per_sample, ubase = (uprev - n_img * p.units_per_sample) * 32;
+    static_for<NTP + 1>([&](auto part_c) {
+      if (ubase + 32 <= p.hw)
+        epi_part(part_c, C1{}, std::true_type{}, acc1, uprev, n_img, ubase);
+      else
+        epi_part(part_c, C1{}, std::false_type{}, acc1, uprev, n_img, ubase);
+    });
+  }
+}
+
+int launch_wsp(const diga_conv_desc* d, const ConvKParams& p, int epi, int id, hipStream_t st) {
+  const int nw = id == 96 ? 4 : 8;       // 96: one wave per SIMD (up to 512 registers: nothing spills at K = 256)
+  DIGA_CHECK_ARG(d->ntaps == 1 && d->stride == 1 && d->dy[0] == 0 && d->dx[0] == 0 && d->H == d->Ho && d->W == d->Wo,
+                 "diga_conv_igemm_bf16: tile %d (weights-stationary, pipelined) is for 1x1 stride-1 convolutions", id);
+  DIGA_CHECK_ARG((d->Cin == 64 || d->Cin == 128 || d->Cin == 256) && d->Cout % 128 == 0 && d->cout_pad == d->Cout,
+                 "diga_conv_igemm_bf16: tile %d needs Cin in {64, 128, 256} and Cout %% 128 == 0 (got %d -> %d)", id, d->Cin, d->Cout);
+  DIGA_CHECK_ARG(epi == EPI_BF16_STATS && p.nterms == 1 && d->splitk == 1 && p.fin_ticket == nullptr,
+                 "diga_conv_igemm_bf16: tile %d has the trunk epilogue only (bf16 output + statistics)", id);
+  const int units_total = d->B * p.units_per_sample, nslices = d->Cout / 128;
+  int groups = 256 / nslices;
+  if (groups < 1) groups = 1;
+  if (groups > cdiv(units_total, nw)) groups = cdiv(units_total, nw);
+  const int upg = cdiv(units_total, groups);
+  groups = cdiv(units_total, upg);
+  const int smem = 128 * d->Cin * 2 + nw * (32 * (64 + 8) * 2 + 2 * 64 * 4);
+  dim3 grid(groups * nslices), block(64 * nw);
+#define DIGA_WSP_LAUNCH(KC, NW)                                                                                         \
+  {                                                                                                                     \
+    static std::once_flag once;                                                                                         \
+    std::call_once(once, [&] {                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wsp_kernel<KC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                128 * KC * 2 + NW * (32 * (64 + 8) * 2 + 2 * 64 * 4));                                                  \
+    });                                                                                                                 \
+    hipLaunchKernelGGL((conv1x1_wsp_kernel<KC, NW>), grid, block, smem, st, p, units_total, upg);                       \
+  }
+  if (nw == 8) {
+    if (d->Cin == 64) DIGA_WSP_LAUNCH(64, 8)
+    else if (d->Cin == 128) DIGA_WSP_LAUNCH(128, 8)
+    else DIGA_WSP_LAUNCH(256, 8)
+  } else {
+    if (d->Cin == 64) DIGA_WSP_LAUNCH(64, 4)
+    else if (d->Cin == 128) DIGA_WSP_LAUNCH(128, 4)
+    else DIGA_WSP_LAUNCH(256, 4)
+  }
+#undef DIGA_WSP_LAUNCH
+  return DIGA_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
 // A-stationary 1x1 convolution with the DAM apply of its INPUT fused (tile id 93): conv3 of a bottleneck taking conv2's RAW
 // output, A = bf16(relu(fma(raw2, scale, shift))) formed ONCE per element in registers -- act2 is never written and read back
 // (VERDICT r2 item 7).  The fused-input forms above repeat the transform for every N tile that re-reads an element (4-8x
@@ -1419,7 +1668,7 @@ const TileCfg kTiles[] = {{1, 128, 128, 4}, {11, 128, 128, 3}, {21, 128, 128, 2}
                           // id 91: conv1x1_ws_kernel (weights-stationary 1x1, Cin <= 256); BM = its 32-row units; id 92: Cin = 512, 64-column slices
                           // id 93: conv1x1_as_kernel (A-stationary 1x1 with the fused DAM apply of its input; fused-input entry point only)
                           {91, 32, 128, 1, 64, false}, {92, 32, 64, 1, 64, false}, {93, 32, 64, 3, 64, false},
-                          {94, 32, 128, 1, 64, false}};
+                          {94, 32, 128, 1, 64, false}, {95, 32, 128, 1, 64, false}, {96, 32, 128, 1, 64, false}};
 
 const TileCfg* find_tile(int id) {
   for (const auto& t : kTiles)
@@ -1599,6 +1848,11 @@ int run_conv(const diga_conv_desc* d, const void* in, const void* wgt, void* out
     }
     if (e) return e;
     DIGA_CHECK_LAUNCH("diga_conv_igemm_bf16_fused_in");
+    return DIGA_OK;
+  }
+  if (t->id == 95 || t->id == 96) {
+    if (int e95 = launch_wsp(d, p, epi, t->id, st)) return e95;
+    DIGA_CHECK_LAUNCH("diga_conv_igemm_bf16");
     return DIGA_OK;
   }
   if (t->id == 91 || t->id == 92 || t->id == 94) {

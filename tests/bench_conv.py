@@ -26,10 +26,10 @@ SHAPES = {
     "l4.c3": (65, 129, 512, 2048, 1, False, 1), "l4.ds": (65, 129, 1024, 2048, 1, False, 1),
 }
 ALL_TILES = [1, 11, 21, 2, 12, 22, 3, 13, 23, 4, 14, 24, 16, 26, 17, 27, 28, 31, 32, 33, 34, 36, 37, 38, 46, 47, 48, 56,
-             57, 58, 61, 64, 66, 67, 91, 92, 94]
+             57, 58, 61, 64, 66, 67, 91, 92, 94, 95, 96]
 MANIFEST = []        # launch order, for aligning rocprofv3 --pmc rows (profiles/pmc_conv.py)
 TILE_MN = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (64, 128), 5: (128, 32), 6: (256, 128), 7: (128, 256), 8: (256, 256)}
-WS_MN = {91: (32, 128), 92: (32, 64), 94: (32, 128)}
+WS_MN = {91: (32, 128), 92: (32, 64), 94: (32, 128), 95: (32, 128), 96: (32, 128)}
 
 
 def run(name, tiles, reps, B=1):

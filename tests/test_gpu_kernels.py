@@ -155,7 +155,7 @@ def test_weights_stationary_1x1_is_bit_identical(B, H, W, Cin, Cout):
 
     ws = 92 if Cin == 512 else 91   # 92: the K = 512 form with 64-column slices
     o0, s0 = run(23)
-    for tile in ((ws,) if Cin == 512 else (91, 94)):      # 94: two 64-column passes per unit, 12 waves per block
+    for tile in ((ws,) if Cin == 512 else (91, 94, 95, 96)):  # 94: two 64-column passes per unit, 12 waves; 95: pipelined halves
         for rep in range(3):        # the kernel counts its own memory operations: screen for a wait that is too lenient
             o1, s1 = run(tile)
             assert not torch.isnan(s1).any()
