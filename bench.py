@@ -467,7 +467,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # DIGA_BENCH_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs than ranks (ranks share a device and
     # the collectives take a host round trip); the measured configuration is always nccl (= RCCL), one rank per GPU
-    backend = os.environ.get("DIGA_BENCH_BACKEND", "nccl")
+    # (also taken by itself when a launcher started more ranks than this box has GPUs, so that the driver's own command line
+    # rehearses instead of failing with "invalid device ordinal")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    backend = os.environ.get("DIGA_BENCH_BACKEND", "nccl" if torch.cuda.device_count() >= local_world else "gloo")
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
