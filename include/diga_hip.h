@@ -56,7 +56,9 @@ typedef struct {
   int32_t out_f32;             /* 0: out = bf16 [M][Cout];  1: out = fp32 [splitk][M][cout_pad] partials */
   int32_t tile;                /* 0 = auto; else tile-config id (csrc/conv_igemm.hip kTiles; 91 = the weights-stationary 1x1
                                   kernel: stride 1, Cin 64 / 128 / 256, Cout % 128 == 0, bf16 output + statistics; 92 = the same kernel for
-                                  Cin 512 with 64-column slices -- both refused with an error for anything else).  Outputs and statistics do not depend on the id. */
+                                  Cin 512 with 64-column slices; 94 / 95 / 96 = measured variants of 91 (two passes with 12 waves; the epilogue pipelined inside the
+                                  wave, 8 / 4 waves), same shapes, kept for A/B runs; 93 = the A-stationary form of diga_conv_igemm_bf16_fused_in -- all refused with
+                                  an error for anything else).  Outputs and statistics do not depend on the id. */
   int32_t nplanes;             /* 0 / 1: bf16 operands (the product path).  2 / 3: verification mode -- `in` is nplanes bf16
                                 * planes [nplanes][B*H*W][Cin] whose SUM is the fp32 activation (hi = bf16(x), lo = bf16(x - hi),
                                 * ...), `wgt` likewise [nplanes][cout_pad][K]; the plane products (a, b) with a + b < nplanes are
