@@ -181,3 +181,31 @@ def test_eval_length_stream_500_frames_exact_mode(synth_params_np):
     assert max(r["norm_err"] for r in rows) <= 1e-4 and max(r["moved"] for r in rows) <= 1e-3, rows
     ref_final = g["ev_run_final"]
     assert float(np.abs(eng.run_proto.cpu().numpy() - ref_final).max() / np.abs(ref_final).max()) <= 1e-4
+
+
+def test_bench_configuration_is_deterministic_under_two_streams(weights):
+    """The measured configuration (two windows of 15 frames on two HIP streams, autotuned tiles incl. the hand-counted-wait kernels):
+    two independent runs of 6 steps (180 frames) end with the SAME BITS of confusion matrix, running prototypes, flags, and of the
+    last step's logits and features -- a wait that is too lenient, or a race between the two streams, would show here as a
+    difference between runs."""
+    from diga_amd.pipeline import StreamWindows
+    K, NW, steps = 15, 2, 6
+    frames = [synth.synth_frame(t, 1, 512, 1024) for t in range(K * NW)]
+    wins = []
+    for w in range(NW):
+        fr = frames[w * K:(w + 1) * K]
+        wins.append((torch.from_numpy(np.concatenate([a for a, _ in fr])).cuda(), torch.from_numpy(np.concatenate([b for _, b in fr])).cuda()))
+    outs = []
+    for run in range(2):
+        sw = StreamWindows(weights, K, NW, 512, 1024, bn_lambda=CFG["bn_lambda"], autotune=True)
+        for _ in range(steps):
+            sw.step(wins, CFG)
+        torch.cuda.synchronize()
+        e0, e1 = sw.engines
+        outs.append([e0.hist.clone(), e0.run_proto.clone(), e0.run_flag.clone(), e0.logits.clone(), e1.logits.clone(),
+                     e0.feat.view(torch.int16).clone(), e1.feat.view(torch.int16).clone(), e1.pred.clone()])
+        del sw
+    for i, (a, b) in enumerate(zip(*outs)):
+        a = torch.nan_to_num(a.float(), nan=-1.0) if a.is_floating_point() else a
+        b = torch.nan_to_num(b.float(), nan=-1.0) if b.is_floating_point() else b
+        assert torch.equal(a, b), i
