@@ -1239,17 +1239,34 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_wsp_kernel(const ConvKParams 
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int n = 0; n < NTP; ++n) am[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // GUIDED (the 4-wave form: one wave per SIMD has nobody to hide its waits, and the registers for it): the weight fragments of K
+    // step k + 1 are read at the top of step k into the other half of fb, and the step is laid out by sched_group_barrier as
+    // [4 LDS reads] 8 x [1 MFMA, 6 vector, 1 LDS write] [the rest] -- left alone the scheduler reads them right before their MFMAs
+    constexpr bool GUIDED = NW == 4;
+    bf16x8 fb[2][NTP];
+    if constexpr (GUIDED) {
+#pragma unroll
+      for (int n = 0; n < NTP; ++n) fb[0][n] = *reinterpret_cast<const bf16x8*>(bB + (H * NTP + n) * 16 * ROWB + ((fq ^ b_swz) << 4));
+    }
     static_for<KS>([&](auto k_c) {
       constexpr int k = decltype(k_c)::value;
-      const int coff = ((4 * k + fq) ^ b_swz) << 4;
-      bf16x8 fb[NTP];
+      constexpr int cur = GUIDED ? (k & 1) : 0;
+      if constexpr (GUIDED) {
+        if constexpr (k + 1 < KS) {
+          const int coff = ((4 * (k + 1) + fq) ^ b_swz) << 4;
 #pragma unroll
-      for (int n = 0; n < NTP; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(bB + (H * NTP + n) * 16 * ROWB + coff);
+          for (int n = 0; n < NTP; ++n) fb[(k + 1) & 1][n] = *reinterpret_cast<const bf16x8*>(bB + (H * NTP + n) * 16 * ROWB + coff);
+        }
+      } else {
+        const int coff = ((4 * k + fq) ^ b_swz) << 4;
+#pragma unroll
+        for (int n = 0; n < NTP; ++n) fb[0][n] = *reinterpret_cast<const bf16x8*>(bB + (H * NTP + n) * 16 * ROWB + coff);
+      }
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const bf16x8 av = __builtin_bit_cast(bf16x8, fa[k][a]);
 #pragma unroll
-        for (int n = 0; n < NTP; ++n) am[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, fb[n], am[a][n], 0, 0, 0);
+        for (int n = 0; n < NTP; ++n) am[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, fb[cur][n], am[a][n], 0, 0, 0);
       }
       if constexpr (H == 1) {      // the unit's last use of this K step's A registers: the next unit's fragments go into them
 #pragma unroll
@@ -1259,7 +1276,20 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_wsp_kernel(const ConvKParams 
         static_for<PPS>([&](auto q_c) {
           epi_part(std::integral_constant<int, k * PPS + decltype(q_c)::value>{}, std::integral_constant<int, 1 - H>{}, full_c, ae, uE, n_img, ubase);
         });
-      __builtin_amdgcn_sched_barrier(0x100);      // only LDS reads (the next step's weight fragments) may move across K steps
+      if constexpr (GUIDED) {
+        if constexpr (k + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, NTP, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * NTP; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if constexpr (EPI) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 6 * PPS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 2 * PPS, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        __builtin_amdgcn_sched_barrier(0x100);    // only LDS reads (the next step's weight fragments) may move across K steps
+      }
     });
   };
   auto is_full = [&](int uE) {
