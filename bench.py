@@ -232,6 +232,54 @@ def miou_vs_reference(weights, dev, fif, nwin, autotune, seed=0):
             "source": f"tests/golden/{os.path.basename(path)}: the reference's forward_and_adapt + Upsample + SegmentationMetric on the same frames (fp32, CPU)"}
 
 
+def pcie_inclusive(args, dev, weights, fif, nwin, steps):
+    """The boundary hands over HOST buffers (`DIGA.test_step(batch)` takes the DataLoader's CPU tensors: fp32 frames, int64 labels):
+    the same step with every frame crossing PCIe inside the timed region -- never `value`, reported beside it.
+      overlapped: diga_amd.pipeline.HostFeeder -- pinned host frames, async H2D on a copy stream into the OTHER of two device input
+                  sets while the current set's HIP graph runs (event-ordered both ways);
+      serial:     copy, then compute, on one stream (what a plain `.cuda()` per batch does)."""
+    from diga_amd import synth
+    from diga_amd.pipeline import HostFeeder, StreamWindows
+    H, W = args.height, args.width
+    sw = StreamWindows(weights, fif, nwin, H, W, bn_lambda=CFG["bn_lambda"], autotune=not args.no_autotune)
+    host = []
+    for s in range(2):
+        hs = []
+        for w in range(nwin):
+            xy = [synth.synth_frame(2000 + (s * nwin + w) * fif + k, 1, H, W) for k in range(fif)]
+            hs.append((torch.from_numpy(np.concatenate([a for a, _ in xy])).pin_memory(),
+                       torch.from_numpy(np.concatenate([b for _, b in xy])).pin_memory()))
+        host.append(hs)
+    nbytes = sum(hx.numel() * hx.element_size() + hy.numel() * hy.element_size() for hx, hy in host[0])
+    fd = HostFeeder(sw, CFG)
+    out = {}
+
+    def overlapped(n):
+        fd.feed(host[0])
+        for i in range(n):
+            fd.run(host[(i + 1) & 1] if i + 1 < n else None)
+
+    def serial(n):                      # the feeder's own buffers and graphs, but nothing travels while a step computes
+        for i in range(n):
+            fd.feed(host[i & 1])
+            fd.run(None)
+            torch.cuda.current_stream().synchronize()
+
+    for mode, fn in (("overlapped", overlapped), ("serial", serial)):
+        fn(4)                           # warm-up (first use of a set runs eagerly and captures its graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[mode] = {"value": round(fif * nwin * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
+                     "h2d_gbs": round(nbytes * steps / dt / 1e9, 2)}
+    out["bytes_per_frame"] = nbytes // (fif * nwin)
+    out["host_buffers"] = "pinned; fp32 frame [3, H, W] + int64 labels [H, W] per frame, as the reference's DataLoader hands them over"
+    del fd, sw
+    return out
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start N FRESH rank processes -- this parent never
     touches a GPU (counting devices does not initialise one) and never replaces itself -- hand rank 0's JSON line through, and
@@ -436,6 +484,7 @@ def main():
     ap.add_argument("--no-latency-mode", action="store_true", help="skip the extra one-frame-per-step measurement")
     ap.add_argument("--no-exact-mode", action="store_true", help="skip the throughput / logit-error leg of the fp32-exact verification mode")
     ap.add_argument("--no-miou", action="store_true", help="skip the mIoU-vs-reference leg (five 30-frame streams + one 500-frame stream through the measured configuration)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (frames handed over in pinned host memory)")
     ap.add_argument("--no-eval-stream", action="store_true", help="skip the 500-frame stream of the mIoU-vs-reference leg (about 20 s)")
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="N=1 only: run the N>1 code path (eager launches, one window, per-layer reduce_slab + RCCL all-reduce + "
@@ -486,7 +535,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29700 + os.getpid() % 200}", rank=0, world_size=1, device_id=dev)
         group = dist.group.WORLD
-        args.no_miou, args.no_latency_mode, args.no_exact_mode = True, True, True
+        args.no_miou, args.no_latency_mode, args.no_exact_mode, args.no_pcie = True, True, True, True
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from diga_amd import synth
@@ -652,6 +701,10 @@ def main():
         # parity-grade throughput: the fp32-exact mode on the same stream (fp32x3 = fp32-grade products, fp32x2 = "bf16x3")
         torch.cuda.empty_cache()
         res["exact_mode"] = [exact_mode(dev, prec, fif, 4, H, W) for prec in ("fp32x2", "fp32x3")]
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_pcie:
+        torch.cuda.empty_cache()
+        res["pcie_inclusive"] = pcie_inclusive(args, dev, weights, fif, nwin, max(10, args.steps // 2))
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_calibration:
         res["calibration"] = calibrate(dev)

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_r3
 mkdir -p $O
 FIF=${FIF:-15}
-Q="--no-cpu-baseline --no-latency-mode --no-calibration --no-miou --no-exact-mode"
+Q="--no-cpu-baseline --no-latency-mode --no-calibration --no-miou --no-exact-mode --no-pcie"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- \
   python3 bench.py --steps 20 --warmup 5 $Q --windows 1 --frames-in-flight $FIF > $O/trace.log 2>&1
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- \

@@ -543,3 +543,35 @@ def test_eval_entry_point_runs_the_stream():
     assert set(a) == {0} and a[0].keys() >= {"miou", "miou16", "miou13", "class_iou"}
     assert a[0]["miou"] == b[0]["miou"] and a[0]["miou16"] == b[0]["miou16"] and a[0]["miou13"] == b[0]["miou13"]
     assert 0.0 < a[0]["miou"] < 100.0
+
+
+def test_host_feeder_is_bit_identical(weights):
+    """HostFeeder (frames handed over in pinned HOST memory, H2D on a copy stream into the input set the running step does not
+    read, one HIP graph per set) == StreamWindows.step on device tensors, bit for bit, over 5 steps (both sets, eager first use
+    and graph replays)."""
+    from diga_amd.pipeline import HostFeeder, StreamWindows
+    K, NW, H, W, steps = 2, 2, 129, 257, 5
+    host = []
+    for i in range(steps):
+        wins = []
+        for w in range(NW):
+            xy = [synth.synth_frame((i * NW + w) * K + t, 1, H, W) for t in range(K)]
+            wins.append((torch.from_numpy(np.concatenate([a for a, _ in xy])).pin_memory(), torch.from_numpy(np.concatenate([b for _, b in xy])).pin_memory()))
+        host.append(wins)
+    ref = StreamWindows(weights, K, NW, H, W, bn_lambda=CFG["bn_lambda"])
+    want = []
+    for wins in host:
+        ref.step([(x.cuda(), y.cuda()) for x, y in wins], CFG)
+        torch.cuda.synchronize()
+        want.append([t.clone() for e in ref.engines for t in (e.probs, e.pred)] + [ref.engines[0].hist.clone(), ref.engines[0].run_proto.clone()])
+    sw = StreamWindows(weights, K, NW, H, W, bn_lambda=CFG["bn_lambda"])
+    fd = HostFeeder(sw, CFG)
+    fd.feed(host[0])
+    for i in range(steps):
+        fd.run(host[i + 1] if i + 1 < steps else None)
+        torch.cuda.synchronize()
+        got = [t for e in sw.engines for t in (e.probs, e.pred)] + [sw.engines[0].hist, sw.engines[0].run_proto]
+        for j, (a, b) in enumerate(zip(got, want[i])):
+            a2 = torch.nan_to_num(a.float(), nan=-1.0) if a.is_floating_point() else a
+            b2 = torch.nan_to_num(b.float(), nan=-1.0) if b.is_floating_point() else b
+            assert torch.equal(a2, b2), (i, j)
