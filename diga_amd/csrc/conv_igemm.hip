@@ -402,6 +402,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvKPar
   if constexpr (DEEP) deep = p.ntaps == 1 && p.nterms == 1 && (nt & 1) == 0 && nt >= 2;
   if constexpr (DEEP) {
     if (deep) {
+#ifdef DIGA_EXP_STAGGER_US  /* experiment only: every other CU's first block starts late, so that the CUs' epilogues (HBM idle) do not coincide */
+      if (blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < 100ll * DIGA_EXP_STAGGER_US) __builtin_amdgcn_s_sleep(32);
+      }
+#endif
       constexpr int NA = 4 + 2 * A_CH;               // loads of one operand set: 2 + 2 affine vectors, A_CH raw, A_CH residual chunks
       constexpr int KCH = 64 / MF, KS = BK / (8 * KCH);
       const bool wb = ntile == 0;
