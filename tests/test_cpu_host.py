@@ -306,3 +306,33 @@ def test_sharded_statistics_protocol_gloo():
         p.join(timeout=60)
     for rank, err, perr, flags_ok in res:
         assert err < 1e-5 and perr < 1e-5 and flags_ok, (rank, err, perr)
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r3_bench.json (the line `python bench.py` printed on the MI355X for this tree) has every key the driver's contract
+    names, the roofline / cpu_baseline objects, and internally consistent numbers."""
+    import json
+    with open(os.path.join(ROOT, "profiles", "r3_bench.json")) as f:
+        lines = [ln for ln in f.read().splitlines() if ln.strip()]
+    assert len(lines) == 1                                   # ONE JSON line
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "frames/s" and d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert "model" not in d["config"]
+    fps = d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)
+    assert abs(fps - d["value"]) / d["value"] < 1e-3          # value = frames of the timed steps / their time
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    assert abs(r["algorithmic_gflop"] / r["kernel_ms"] - r["achieved"]) / r["achieved"] < 1e-3     # GFLOP / ms = TFLOP/s
+    assert r["traffic"] is None or r["traffic"] > 0.8 * r["algorithmic_gflop"] * 1e9 / 500           # bytes, same order as the algorithmic ones
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"]
+    h = d["roofline_hbm"]
+    assert h["bound"] == "hbm" and abs(h["algorithmic_bytes"] / (h["kernel_ms"] * 1e-3) / 1e9 - h["achieved"]) / h["achieved"] < 1e-3
